@@ -1,0 +1,78 @@
+"""Regenerates the INPUTS of the golden cases from seeds (the fixtures hold only the reference's
+outputs + small arrays).  Mirrors tools/make_golden.py, which produced tests/golden/*.npz by
+running the reference."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def blobs_f32(n, d, seed, n_centers=32, scale=4.0):
+    rng = np.random.default_rng(seed)
+    centers = rng.normal(0.0, scale, size=(n_centers, d))
+    lab = rng.integers(0, n_centers, size=n)
+    X = centers[lab] + rng.normal(0.0, 1.0, size=(n, d))
+    return X.astype(np.float32), lab
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, f"{name}.npz"))
+
+
+def case_X(name):
+    """-> (X, y or None)"""
+    if name in ("digits_f64", "digits_clf"):
+        from sklearn.datasets import load_digits
+
+        dg = load_digits()
+        return dg.data, (dg.target if name == "digits_clf" else None)
+    if name == "digits_f32":
+        from sklearn.datasets import load_digits
+
+        return load_digits().data.astype(np.float32), None
+    if name == "blobs_dead":
+        from sklearn.datasets import make_blobs
+
+        return make_blobs(n_samples=3000, n_features=16, centers=8, random_state=1)[0], None
+    if name == "lowd_linear":
+        return np.random.default_rng(5).normal(size=(2000, 3)) * np.array([3.0, 1.0, 0.3]), None
+    if name == "ties_int":
+        Xt = np.random.default_rng(11).integers(0, 4, size=(600, 20)).astype(np.float64)
+        Xt[300:] = Xt[:300]
+        return Xt, None
+    if name == "frozen_c2_f32":
+        return blobs_f32(20000, 784, 1002)[0], None
+    if name == "frozen_c3_f32":
+        return blobs_f32(30000, 128, 1003)[0], None
+    if name == "frozen_f64":
+        return blobs_f32(8000, 100, 77)[0].astype(np.float64) * 1.0000001, None
+    raise KeyError(name)
+
+
+FIT_CASES = ["digits_f64", "digits_f32", "blobs_dead", "lowd_linear", "ties_int", "digits_clf"]
+FROZEN_CASES = ["frozen_c2_f32", "frozen_c3_f32", "frozen_f64"]
+
+EST_KWARGS = {
+    "digits_f64": dict(random_state=0),
+    "digits_f32": dict(random_state=0),
+    "digits_clf": dict(random_state=0),
+    "blobs_dead": dict(random_state=0, spreading_factor=0.99, max_neurons=400, n_iter=60,
+                       convergence_iter=2),
+    "lowd_linear": dict(random_state=3, n_iter=40, decay_function="linear", max_neurons=60,
+                        spreading_factor=0.3, sigma_start=2.0, sigma_end=0.5,
+                        coarse_training_frac=0.6, convergence_iter=3),
+    "ties_int": dict(random_state=1, n_iter=12, max_neurons=30),
+}
+
+
+def frozen_W(name, X):
+    g = load(name)
+    return X[g["sel"]].astype(np.float64), int(g["rows"]), int(g["cols"])
+
+
+def lattice_hops(rows, cols):
+    """Hop (Manhattan) distances of a full rows x cols lattice, node order (i, j) row-major."""
+    ii, jj = np.divmod(np.arange(rows * cols), cols)
+    return (np.abs(ii[:, None] - ii[None, :]) + np.abs(jj[:, None] - jj[None, :])).astype(
+        np.float64)
