@@ -1,0 +1,103 @@
+"""ctypes binding of ``libdbgsom_hip.so`` (C ABI: ``include/dbgsom_hip.h``).
+
+The product path has NO CPU fallback: :func:`load` raises when the HIP library is missing, and
+``dbgsom_amd.backend.HipBackend`` raises when no MI355X is visible.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libdbgsom_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "dbgsom_hip.h")
+
+F32, F64 = 0, 1
+CENTRES_COMPACT, CENTRES_ALIGNED = 0, 1
+LAYOUTS = {"compact": CENTRES_COMPACT, "aligned": CENTRES_ALIGNED}
+MAX_PROTOTYPES = 16000
+
+_i64, _vp, _ci, _dbl, _sz = (ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+                             ctypes.c_size_t)
+
+# name -> (restype, argtypes); every symbol declared in include/dbgsom_hip.h
+SIGNATURES = {
+    "dbgsom_abi_version": (_ci, []),
+    "dbgsom_last_error": (ctypes.c_char_p, []),
+    "dbgsom_device_count": (_ci, [ctypes.POINTER(_ci)]),
+    "dbgsom_row_sqnorms": (_ci, [_vp, _ci, _i64, _i64, _i64, _vp, _vp]),
+    "dbgsom_bmu": (_ci, [_vp, _ci, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _ci, _ci, _vp, _vp, _vp]),
+    "dbgsom_exp_similarity": (_ci, [_vp, _i64, _dbl, _vp, _vp]),
+    "dbgsom_accumulate_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "dbgsom_accumulate": (_ci, [_vp, _ci, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
+                                _sz, _vp]),
+    "dbgsom_smooth_workspace_bytes": (_sz, [_i64, _i64]),
+    "dbgsom_smooth": (_ci, [_vp, _i64, _i64, _vp, _dbl, _ci, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dbgsom_ctx_create": (_ci, [_ci, ctypes.POINTER(_vp)]),
+    "dbgsom_ctx_destroy": (_ci, [_vp]),
+    "dbgsom_ctx_load": (_ci, [_vp, _vp, _ci, _i64, _i64]),
+    "dbgsom_ctx_set_topology": (_ci, [_vp, _vp, _i64]),
+    "dbgsom_ctx_bmu": (_ci, [_vp, _vp, _i64, _ci, _ci, _vp, _vp]),
+    "dbgsom_ctx_bmu_query": (_ci, [_vp, _vp, _ci, _i64, _i64, _vp, _i64, _ci, _ci, _vp, _vp]),
+    "dbgsom_ctx_epoch": (_ci, [_vp, _vp, _i64, _ci, _dbl, _dbl, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class DbgsomNativeError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+    def __init__(self, fn, code, msg):
+        super().__init__(f"{fn} failed ({code}): {msg}")
+        self.code = code
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``dbgsom_amd/csrc/libdbgsom_hip.so`` (hipcc
+    cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "-j4", "libdbgsom_hip.so"], stdout=out)
+    return LIB_PATH
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C dbgsom_amd/csrc`). "
+            "dbgsom_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dbgsom_abi_version() != 1:
+        raise RuntimeError(f"ABI version mismatch: library {lib.dbgsom_abi_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(fn_name: str, rc: int) -> None:
+    if rc != 0:
+        msg = load().dbgsom_last_error()
+        err = DbgsomNativeError(fn_name, rc, msg.decode(errors="replace") if msg else "")
+        if rc == -1:
+            raise ValueError(str(err))
+        raise err
+
+
+def call(fn_name: str, *args):
+    check(fn_name, getattr(load(), fn_name)(*args))
+
+
+def device_count() -> int:
+    n = _ci(0)
+    call("dbgsom_device_count", ctypes.byref(n))
+    return n.value

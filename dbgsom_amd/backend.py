@@ -1,0 +1,322 @@
+"""Hot-path backends: the object the estimator calls once per epoch.
+
+``HipBackend`` drives the hand-written gfx950 kernels through the C ABI
+(``include/dbgsom_hip.h``) with PyTorch used only as plumbing: device memory, the current HIP
+stream, and ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI) for the one all-reduce of
+the per-prototype sums per epoch.  There is no CPU fallback: constructing it without the built
+library or without a GPU raises.
+
+The four operations mirror the private methods of the reference's ``BaseSom``
+(``dbgsom/BaseSom.py``):
+
+    bmu(W, k)                    _get_winning_neurons(data, n_bmu)        :446-464
+    exp_similarity(dist, gamma)  _calculate_exp_similarity(distances)     :533-538
+    update(...)                  _update_weights(sample_weights, winners, data) :470-523
+                                 + _write_accumulative_error              :541-561
+    epoch(...)                   the fused body of _grow_som              :403-407
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _native
+
+
+@dataclass
+class EpochResult:
+    new_weights: np.ndarray      # (M, d) float64
+    change_total: float          # sum_j |W_j - W'_j|_2
+    errors: np.ndarray           # (M,) per-neuron sum of BMU distances
+    activations: np.ndarray      # (M,) hit counts
+    winners: Optional[np.ndarray] = None    # (N_local,) int64
+    distances: Optional[np.ndarray] = None  # (N_local,) float64
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """Contiguous row shard [lo, hi) of rank `rank` (row-shard X once)."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def dist_info():
+    """(rank, world) of the default process group, (0, 1) when torch.distributed is not up."""
+    try:
+        import torch.distributed as td
+
+        if td.is_available() and td.is_initialized():
+            return td.get_rank(), td.get_world_size()
+    except ImportError:  # pragma: no cover
+        pass
+    return 0, 1
+
+
+class HotPathBackend:
+    """Epoch template shared by the HIP backend and the test-only oracle backend:
+    local per-prototype sums -> (all-reduce across sample shards) -> smoothing."""
+
+    name = "abstract"
+
+    # -- to implement -------------------------------------------------------------------------
+    def load(self, X):  # upload-once residency
+        raise NotImplementedError
+
+    def bmu(self, W, k=1, X=None):
+        raise NotImplementedError
+
+    def exp_similarity(self, distances, gamma):
+        raise NotImplementedError
+
+    def _local_sums(self, W, gamma, want_assignments):
+        """-> (sums tensor [M*(d+3)] float64 = [S | K | a | E], winners, distances)"""
+        raise NotImplementedError
+
+    def _sums_from(self, W, sample_weights, winners, distances):
+        raise NotImplementedError
+
+    def _smooth(self, sums, W, hop, sigma, layout):
+        """-> (new_weights ndarray, change_total float, errors ndarray, activations ndarray)"""
+        raise NotImplementedError
+
+    # -- shared -------------------------------------------------------------------------------
+    def _all_reduce(self, sums):
+        rank, world = dist_info()
+        if world > 1:
+            import torch.distributed as td
+
+            td.all_reduce(sums, op=td.ReduceOp.SUM)  # one collective per epoch
+        return sums
+
+    def epoch(self, W, hop, sigma, gamma, layout="compact", want_assignments=False):
+        sums, win, dist = self._local_sums(W, gamma, want_assignments)
+        sums = self._all_reduce(sums)
+        Wn, chg, E, a = self._smooth(sums, W, hop, sigma, layout)
+        return EpochResult(Wn, chg, E, a, win, dist)
+
+    def update(self, W, hop, sigma, sample_weights, winners, distances, layout="compact"):
+        sums = self._sums_from(W, sample_weights, winners, distances)
+        sums = self._all_reduce(sums)
+        return self._smooth(sums, W, hop, sigma, layout)
+
+    def release(self):
+        pass
+
+
+def _x_dtype_code(dt) -> int:
+    if dt == np.float32:
+        return _native.F32
+    if dt == np.float64:
+        return _native.F64
+    raise ValueError(f"samples must be float32 or float64, got {dt}")
+
+
+class HipBackend(HotPathBackend):
+    """MI355X backend.  One instance per process / per GPU."""
+
+    name = "hip"
+
+    def __init__(self, device: Optional[int] = None):
+        self._lib = _native.load()  # raises when the extension is not built
+        import torch
+
+        if not torch.cuda.is_available() or _native.device_count() < 1:
+            raise RuntimeError(
+                "dbgsom_amd.HipBackend needs a visible AMD GPU (MI355X / gfx950); none found. "
+                "There is no CPU fallback in the product path.")
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+        self._torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self._X = None
+        self._xx = None
+        self._x_np_dtype = None
+        self._hop_key = None
+        self._hop_dev = None
+        self._ws = {}
+
+    # -- helpers --------------------------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def _buf(self, key, nbytes):
+        """Reusable byte workspace (torch caching allocator blocks are >= 512-B aligned)."""
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = self._torch.empty(max(int(nbytes), 256), dtype=self._torch.uint8,
+                                  device=self.device)
+            self._ws[key] = t
+        return t
+
+    def _dev_f64(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return self._torch.from_numpy(a).to(self.device)
+
+    def _norms(self, t, dtype_code, rows, d):
+        out = self._torch.empty(rows, dtype=self._torch.float64, device=self.device)
+        _native.call("dbgsom_row_sqnorms", self._p(t), dtype_code, rows, d, d, self._p(out),
+                     self._stream())
+        return out
+
+    def _round_f32(self, W, xdtype):
+        # float32 samples AND float32 prototypes: the reference's engine returns float32-rounded
+        # distances (epoch 0 of a float32 fit).  Every other mix is full float64.
+        return int(xdtype == np.float32 and np.asarray(W).dtype == np.float32)
+
+    # -- a8: residency --------------------------------------------------------------------------
+    def load(self, X):
+        X = np.ascontiguousarray(X)
+        code = _x_dtype_code(X.dtype)
+        if X.ndim != 2 or X.shape[0] < 1:
+            raise ValueError("X must be a non-empty 2-D array")
+        self._x_np_dtype = X.dtype
+        self._X = self._torch.from_numpy(X).to(self.device)
+        self._xx = self._norms(self._X, code, X.shape[0], X.shape[1])
+        return self
+
+    def load_device(self, X_dev):
+        """Adopt samples that already live in HBM (bench: generated on the device)."""
+        torch = self._torch
+        if X_dev.dtype not in (torch.float32, torch.float64) or X_dev.dim() != 2:
+            raise ValueError("X_dev must be a 2-D float32/float64 tensor")
+        X_dev = X_dev.contiguous()
+        self._x_np_dtype = np.dtype(np.float32 if X_dev.dtype == torch.float32 else np.float64)
+        self._X = X_dev
+        self._xx = self._norms(X_dev, _x_dtype_code(self._x_np_dtype), X_dev.shape[0],
+                               X_dev.shape[1])
+        return self
+
+    @property
+    def n_samples(self):
+        return int(self._X.shape[0])
+
+    def _require_loaded(self):
+        if self._X is None:
+            raise RuntimeError("HipBackend: call load(X) first")
+
+    # -- a1 -------------------------------------------------------------------------------------
+    def _bmu_dev(self, Xd, xxd, xdtype, Wd, wwd, k, round_f32):
+        torch = self._torch
+        N, d = Xd.shape
+        M = Wd.shape[0]
+        idx = torch.empty((N, k), dtype=torch.int64, device=self.device)
+        dist = torch.empty((N, k), dtype=torch.float64, device=self.device)
+        _native.call("dbgsom_bmu", self._p(Xd), _x_dtype_code(xdtype), N, d, d, self._p(xxd),
+                     self._p(Wd), M, self._p(wwd), k, round_f32, self._p(idx), self._p(dist),
+                     self._stream())
+        return dist, idx
+
+    def bmu(self, W, k=1, X=None):
+        """-> (distances, winners) like BaseSom._get_winning_neurons: shape (N,) for k=1,
+        (N, k) otherwise."""
+        W = np.asarray(W)
+        if X is None:
+            self._require_loaded()
+            Xd, xxd, xdtype = self._X, self._xx, self._x_np_dtype
+        else:
+            X = np.ascontiguousarray(X)
+            xdtype = X.dtype
+            Xd = self._torch.from_numpy(X).to(self.device)
+            xxd = self._norms(Xd, _x_dtype_code(xdtype), X.shape[0], X.shape[1])
+        if W.ndim != 2 or W.shape[1] != Xd.shape[1]:
+            raise ValueError("prototype / sample feature mismatch")
+        Wd = self._dev_f64(W)
+        wwd = self._norms(Wd, _native.F64, W.shape[0], W.shape[1])
+        dist, idx = self._bmu_dev(Xd, xxd, xdtype, Wd, wwd, k, self._round_f32(W, xdtype))
+        dist, idx = dist.cpu().numpy(), idx.cpu().numpy()
+        if k == 1:
+            return dist.reshape(-1), idx.reshape(-1)
+        return dist, idx
+
+    # -- a2 -------------------------------------------------------------------------------------
+    def _exp_similarity_dev(self, dist_dev, gamma):
+        kw = self._torch.empty_like(dist_dev)
+        _native.call("dbgsom_exp_similarity", self._p(dist_dev), dist_dev.numel(), float(gamma),
+                     self._p(kw), self._stream())
+        return kw
+
+    def exp_similarity(self, distances, gamma):
+        dd = self._dev_f64(np.asarray(distances).reshape(-1))
+        return self._exp_similarity_dev(dd, gamma).cpu().numpy()
+
+    # -- a3 / a4 / a7 ---------------------------------------------------------------------------
+    def _accumulate_dev(self, idx_dev, kw_dev, dist_dev, M):
+        torch = self._torch
+        N, d = self._X.shape
+        if M > _native.MAX_PROTOTYPES:
+            raise ValueError(f"M={M} exceeds DBGSOM_MAX_PROTOTYPES={_native.MAX_PROTOTYPES}")
+        sums = torch.empty(M * (d + 3), dtype=torch.float64, device=self.device)
+        need = self._lib.dbgsom_accumulate_workspace_bytes(N, d, M)
+        ws = self._buf("acc", need)
+        status = self._buf("status", 256)
+        _native.call("dbgsom_accumulate", self._p(self._X), _x_dtype_code(self._x_np_dtype), N, d,
+                     d, self._p(idx_dev), self._p(kw_dev), self._p(dist_dev), M, self._p(sums),
+                     self._p(status), self._p(ws), ws.numel(), self._stream())
+        return sums
+
+    def _local_sums(self, W, gamma, want_assignments):
+        self._require_loaded()
+        W = np.asarray(W)
+        Wd = self._dev_f64(W)
+        self._W_dev = Wd
+        wwd = self._norms(Wd, _native.F64, W.shape[0], W.shape[1])
+        dist, idx = self._bmu_dev(self._X, self._xx, self._x_np_dtype, Wd, wwd, 1,
+                                  self._round_f32(W, self._x_np_dtype))
+        dist, idx = dist.view(-1), idx.view(-1)
+        kw = self._exp_similarity_dev(dist, gamma)
+        sums = self._accumulate_dev(idx, kw, dist, W.shape[0])
+        if want_assignments:
+            return sums, idx.cpu().numpy(), dist.cpu().numpy()
+        return sums, None, None
+
+    def _sums_from(self, W, sample_weights, winners, distances):
+        self._require_loaded()
+        torch = self._torch
+        self._W_dev = self._dev_f64(W)
+        idx = torch.from_numpy(np.ascontiguousarray(winners, dtype=np.int64)).to(self.device)
+        kw = self._dev_f64(sample_weights)
+        dist = self._dev_f64(distances)
+        return self._accumulate_dev(idx, kw, dist, np.asarray(W).shape[0])
+
+    # -- a5 / a6 --------------------------------------------------------------------------------
+    def _hop(self, hop):
+        # the estimator hands over the SAME array object until the lattice changes
+        if self._hop_dev is None or hop is not self._hop_key:
+            self._hop_dev = self._torch.from_numpy(
+                np.ascontiguousarray(hop, dtype=np.float32)).to(self.device)
+            self._hop_key = hop
+        return self._hop_dev
+
+    def _smooth(self, sums, W, hop, sigma, layout):
+        torch = self._torch
+        W = np.asarray(W)
+        M, d = W.shape
+        Wd = getattr(self, "_W_dev", None)
+        if Wd is None or tuple(Wd.shape) != (M, d):
+            Wd = self._dev_f64(W)
+        hop_d = self._hop(hop)
+        if tuple(hop_d.shape) != (M, M):
+            raise ValueError("hop matrix must be (M, M)")
+        Wn = torch.empty((M, d), dtype=torch.float64, device=self.device)
+        chg = torch.empty(1, dtype=torch.float64, device=self.device)
+        need = self._lib.dbgsom_smooth_workspace_bytes(M, d)
+        ws = self._buf("smooth", need)
+        _native.call("dbgsom_smooth", self._p(sums), M, d, self._p(hop_d), float(sigma),
+                     _native.LAYOUTS[layout], self._p(Wd), self._p(Wn), self._p(chg), self._p(ws),
+                     ws.numel(), self._stream())
+        tail = sums[M * d:].cpu().numpy()
+        status = int(self._ws["status"][:4].view(torch.int32).item()) if "status" in self._ws else 0
+        if status:
+            raise _native.DbgsomNativeError("dbgsom_accumulate", -5, "winner index out of range")
+        return Wn.cpu().numpy(), float(chg.item()), tail[2 * M:3 * M].copy(), tail[M:2 * M].copy()
+
+    def release(self):
+        self._X = self._xx = self._hop_dev = None
+        self._ws.clear()

@@ -1,0 +1,326 @@
+// Per-neuron sums of one epoch on gfx950: S_j = sum kw_i x_i, K_j = sum kw_i, a_j = hits,
+// E_j = sum dist_i, id-indexed and bitwise reproducible.
+//
+// Replaces (reference dbgsom/BaseSom.py)
+//   :488-489    argsort(winners) / unique(return_index)          -> stable counting sort
+//   :1028-1055  numba_voronoi_set_centers (numerator/denominator) -> ordered segmented sums
+//   :500-503    neuron_activations                                -> histogram counts
+//   :1058-1073  numba_quantization_error (serial semantics)       -> ordered segmented sum
+//
+// HBM-bound: X is streamed exactly once (row gathers of whole contiguous rows, 16 B per lane),
+// everything else is O(N) integers or O(chunks * d).  No floating-point atomics: samples are
+// bucketed by winner with a stable counting sort (per-workgroup LDS histograms + a column scan),
+// each neuron's list is cut into chunks of <= CH rows, one workgroup sums one chunk in list
+// order, and a second pass adds a neuron's chunk partials in chunk order.
+#include "common.h"
+
+namespace dbgsom {
+
+constexpr int AT = 256;          // threads per workgroup
+constexpr int HS = 2048;         // samples per histogram / scatter workgroup
+constexpr int CH = 128;          // rows per segmented-sum chunk
+
+struct AccWs {
+    int32_t *order;       // N          sample ids, bucketed by winner, stable
+    uint32_t *blk;        // nb * M     per-workgroup histograms -> exclusive block offsets
+    uint32_t *count;      // M
+    uint32_t *seg_start;  // M + 1
+    uint32_t *chunk_pre;  // M + 1      exclusive scan of ceil(count / CH)
+    double *slab;         // maxchunks * (d + 2)   [partial S | partial K | partial E]
+    int64_t nb, maxchunks;
+};
+
+static size_t carve(AccWs *w, char *base, int64_t N, int64_t d, int64_t M) {
+    const int64_t nb = (N + HS - 1) / HS;
+    const int64_t maxchunks = (N + CH - 1) / CH + M;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t o_order = take((size_t)N * 4);
+    const size_t o_blk = take((size_t)nb * M * 4);
+    const size_t o_count = take((size_t)M * 4);
+    const size_t o_seg = take((size_t)(M + 1) * 4);
+    const size_t o_chunk = take((size_t)(M + 1) * 4);
+    const size_t o_slab = take((size_t)maxchunks * (d + 2) * 8);
+    if (w) {
+        w->order = (int32_t *)(base + o_order);
+        w->blk = (uint32_t *)(base + o_blk);
+        w->count = (uint32_t *)(base + o_count);
+        w->seg_start = (uint32_t *)(base + o_seg);
+        w->chunk_pre = (uint32_t *)(base + o_chunk);
+        w->slab = (double *)(base + o_slab);
+        w->nb = nb;
+        w->maxchunks = maxchunks;
+    }
+    return off;
+}
+
+size_t accumulate_workspace_bytes(int64_t N, int64_t d, int64_t M) {
+    if (N < 0 || d < 1 || M < 1) return 0;
+    return carve(nullptr, nullptr, N, d, M);
+}
+
+// ---- 1. per-workgroup histogram of winners ---------------------------------------------------
+__global__ __launch_bounds__(AT) void hist_kernel(const int64_t *__restrict__ win, int64_t N,
+                                                  int M, uint32_t *__restrict__ blk,
+                                                  int32_t *__restrict__ status) {
+    extern __shared__ uint32_t h[];
+    for (int j = threadIdx.x; j < M; j += AT) h[j] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * HS;
+    for (int t = threadIdx.x; t < HS; t += AT) {
+        const int64_t i = base + t;
+        if (i < N) {
+            const int64_t j = win[i];
+            if (j >= 0 && j < M) atomicAdd(&h[j], 1u);
+            else if (status) atomicOr(status, 1);
+        }
+    }
+    __syncthreads();
+    uint32_t *dst = blk + (size_t)blockIdx.x * M;
+    for (int j = threadIdx.x; j < M; j += AT) dst[j] = h[j];
+}
+
+// ---- 2. column scan over workgroups: blk -> exclusive offsets, count[j] ----------------------
+__global__ void colscan_kernel(uint32_t *__restrict__ blk, int64_t nb, int M,
+                               uint32_t *__restrict__ count) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    uint32_t run = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+        const uint32_t c = blk[(size_t)b * M + j];
+        blk[(size_t)b * M + j] = run;
+        run += c;
+    }
+    count[j] = run;
+}
+
+// ---- 3. exclusive scans over the M neurons (one workgroup) -----------------------------------
+__global__ __launch_bounds__(1024) void segscan_kernel(const uint32_t *__restrict__ count, int M,
+                                                       uint32_t *__restrict__ seg_start,
+                                                       uint32_t *__restrict__ chunk_pre) {
+    __shared__ uint32_t sa[1024], sb[1024];
+    const int t = threadIdx.x;
+    const int per = (M + 1023) / 1024;
+    const int lo = t * per, hi = min(M, lo + per);
+    uint32_t a = 0, b = 0;
+    for (int j = lo; j < hi; ++j) { a += count[j]; b += (count[j] + CH - 1) / CH; }
+    sa[t] = a; sb[t] = b;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t ra = 0, rb = 0;
+        for (int u = 0; u < 1024; ++u) {
+            const uint32_t ta = sa[u], tb = sb[u];
+            sa[u] = ra; sb[u] = rb;
+            ra += ta; rb += tb;
+        }
+        seg_start[M] = ra;
+        chunk_pre[M] = rb;
+    }
+    __syncthreads();
+    a = sa[t]; b = sb[t];
+    for (int j = lo; j < hi; ++j) {
+        seg_start[j] = a; chunk_pre[j] = b;
+        a += count[j]; b += (count[j] + CH - 1) / CH;
+    }
+}
+
+// ---- 4. stable scatter of sample ids into their neuron's segment -----------------------------
+__global__ __launch_bounds__(AT) void scatter_kernel(const int64_t *__restrict__ win, int64_t N,
+                                                     int M, const uint32_t *__restrict__ blk,
+                                                     const uint32_t *__restrict__ seg_start,
+                                                     int32_t *__restrict__ order) {
+    extern __shared__ uint32_t cnt[];  // M running write positions of this workgroup
+    __shared__ int keys[AT];
+    const uint32_t *off = blk + (size_t)blockIdx.x * M;
+    for (int j = threadIdx.x; j < M; j += AT) cnt[j] = seg_start[j] + off[j];
+    const int64_t base = (int64_t)blockIdx.x * HS;
+    const int t = threadIdx.x;
+    for (int r = 0; r < HS / AT; ++r) {
+        const int64_t i = base + r * AT + t;
+        int key = -1;
+        if (i < N) {
+            const int64_t j = win[i];
+            if (j >= 0 && j < M) key = (int)j;
+        }
+        __syncthreads();  // cnt is up to date and keys[] is no longer being read
+        keys[t] = key;
+        __syncthreads();
+        int lower = 0, higher = 0;
+        if (key >= 0) {
+            for (int u = 0; u < AT; ++u) {
+                const int ku = keys[u];
+                lower += (ku == key && u < t);
+                higher += (ku == key && u > t);
+            }
+            order[cnt[key] + lower] = (int32_t)i;
+        }
+        __syncthreads();  // every position of this round has been read from cnt
+        if (key >= 0 && higher == 0) cnt[key] += (uint32_t)(lower + 1);  // one thread per key
+    }
+}
+
+// ---- 5. one workgroup sums one chunk (<= CH rows of one neuron) in list order ----------------
+template <typename XT, int VEC>
+__global__ __launch_bounds__(AT) void segsum_kernel(
+    const XT *__restrict__ X, int d, int64_t ldx, const int32_t *__restrict__ order,
+    const double *__restrict__ kw, const double *__restrict__ dist,
+    const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ count,
+    const uint32_t *__restrict__ chunk_pre, int M, double *__restrict__ slab) {
+    __shared__ int32_t rows_s[CH];
+    __shared__ double kw_s[CH];
+    __shared__ double dist_s[CH];
+    __shared__ double red[AT * VEC];
+    __shared__ uint32_t info[3];
+    const int tid = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (c >= chunk_pre[M]) return;  // uniform per workgroup
+    if (tid == 0) {
+        int lo = 0, hi = M;  // last j with chunk_pre[j] <= c
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (chunk_pre[mid] <= c) lo = mid; else hi = mid;
+        }
+        const uint32_t begin = seg_start[lo] + (c - chunk_pre[lo]) * CH;
+        const uint32_t end = min(begin + (uint32_t)CH, seg_start[lo] + count[lo]);
+        info[0] = begin; info[1] = end - begin;
+    }
+    __syncthreads();
+    const uint32_t begin = info[0];
+    const int n = (int)info[1];
+    if (tid < n) {
+        const int32_t r = order[begin + tid];
+        rows_s[tid] = r;
+        kw_s[tid] = kw[r];
+        dist_s[tid] = dist[r];
+    }
+    __syncthreads();
+    double *out = slab + (size_t)c * (d + 2);
+    if (tid == AT - 1) {  // the scalar partials, in list order
+        double sk = 0.0, se = 0.0;
+        for (int p = 0; p < n; ++p) { sk += kw_s[p]; se += dist_s[p]; }
+        out[d] = sk;
+        out[d + 1] = se;
+    }
+    const int Q = d / VEC;  // column groups (VEC divides d by construction)
+    if (Q >= AT) {
+        for (int q = tid; q < Q; q += AT) {
+            double acc[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
+#pragma unroll 4
+            for (int p = 0; p < n; ++p) {
+                const XT *src = X + (int64_t)rows_s[p] * ldx + (int64_t)q * VEC;
+                const double w = kw_s[p];
+                XT v[VEC];
+                if constexpr (VEC == 4) { const float4 t4 = *reinterpret_cast<const float4 *>(src); v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w; }
+                else if constexpr (VEC == 2) { const double2 t2 = *reinterpret_cast<const double2 *>(src); v[0] = t2.x; v[1] = t2.y; }
+                else { v[0] = src[0]; }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += w * (double)v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) out[q * VEC + e] = acc[e];
+        }
+    } else {
+        const int RL = AT / Q;  // row lanes working side by side on the same column group
+        const int rl = tid / Q, q = tid - rl * Q;
+        double acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
+        if (rl < RL) {
+#pragma unroll 4
+            for (int p = rl; p < n; p += RL) {
+                const XT *src = X + (int64_t)rows_s[p] * ldx + (int64_t)q * VEC;
+                const double w = kw_s[p];
+                XT v[VEC];
+                if constexpr (VEC == 4) { const float4 t4 = *reinterpret_cast<const float4 *>(src); v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w; }
+                else if constexpr (VEC == 2) { const double2 t2 = *reinterpret_cast<const double2 *>(src); v[0] = t2.x; v[1] = t2.y; }
+                else { v[0] = src[0]; }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += w * (double)v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) red[(rl * Q + q) * VEC + e] = acc[e];
+        }
+        __syncthreads();
+        if (rl == 0) {  // row lanes are added in lane order
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                double s = red[q * VEC + e];
+                for (int u = 1; u < RL; ++u) s += red[(u * Q + q) * VEC + e];
+                out[q * VEC + e] = s;
+            }
+        }
+    }
+}
+
+// ---- 6. add each neuron's chunk partials in chunk order --------------------------------------
+__global__ __launch_bounds__(AT) void finalize_kernel(const double *__restrict__ slab, int d,
+                                                      int M, const uint32_t *__restrict__ count,
+                                                      const uint32_t *__restrict__ chunk_pre,
+                                                      double *__restrict__ sums) {
+    const int j = blockIdx.x;
+    const uint32_t c0 = chunk_pre[j], c1 = chunk_pre[j + 1];
+    double *S = sums + (size_t)j * d;
+    double *Kp = sums + (size_t)M * d, *ap = Kp + M, *Ep = ap + M;
+    for (int col = threadIdx.x; col < d + 2; col += AT) {
+        double s = 0.0;
+        for (uint32_t c = c0; c < c1; ++c) s += slab[(size_t)c * (d + 2) + col];
+        if (col < d) S[col] = s;
+        else if (col == d) Kp[j] = s;
+        else Ep[j] = s;
+    }
+    if (threadIdx.x == 0) ap[j] = (double)count[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                      const int64_t *idx, const double *kw, const double *dist, int64_t M,
+                      double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s) {
+    DBGSOM_REQUIRE(x_dtype == DBGSOM_F32 || x_dtype == DBGSOM_F64, "x_dtype must be DBGSOM_F32/F64");
+    DBGSOM_REQUIRE(N >= 0 && N < 0x7fffffff && d >= 1 && d <= 0x7ffffff0 && ldx >= d, "bad sample shape");
+    DBGSOM_REQUIRE(M >= 1 && M <= DBGSOM_MAX_PROTOTYPES, "M outside [1, DBGSOM_MAX_PROTOTYPES]");
+    DBGSOM_REQUIRE(sums, "null sums");
+    if (status) DBGSOM_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), s));
+    if (N == 0) {
+        DBGSOM_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)M * (d + 3) * sizeof(double), s));
+        return DBGSOM_OK;
+    }
+    DBGSOM_REQUIRE(X && idx && kw && dist && ws, "null pointer");
+    DBGSOM_REQUIRE(is_aligned(ws, 256), "workspace must be 256-byte aligned");
+    if (ws_bytes < accumulate_workspace_bytes(N, d, M)) {
+        set_error("dbgsom_accumulate: workspace too small (%zu < %zu)", ws_bytes,
+                  accumulate_workspace_bytes(N, d, M));
+        return DBGSOM_ENOMEM;
+    }
+    AccWs w;
+    carve(&w, (char *)ws, N, d, M);
+    const int Mi = (int)M, di = (int)d;
+
+    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)w.nb), dim3(AT), (size_t)M * 4, s, idx, N, Mi,
+                       w.blk, status);
+    hipLaunchKernelGGL(colscan_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, w.blk,
+                       w.nb, Mi, w.count);
+    hipLaunchKernelGGL(segscan_kernel, dim3(1), dim3(1024), 0, s, w.count, Mi, w.seg_start,
+                       w.chunk_pre);
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)w.nb), dim3(AT), (size_t)M * 4, s,
+                       idx, N, Mi, w.blk, w.seg_start, w.order);
+
+    const size_t xe = (x_dtype == DBGSOM_F32) ? 4 : 8;
+    const bool al16 = is_aligned(X, 16) && ((ldx * xe) % 16 == 0);
+    dim3 grid((unsigned)w.maxchunks), block(AT);
+#define DBGSOM_SEGSUM(XT, V)                                                                    \
+    hipLaunchKernelGGL((segsum_kernel<XT, V>), grid, block, 0, s, (const XT *)X, di, ldx, w.order, \
+                       kw, dist, w.seg_start, w.count, w.chunk_pre, Mi, w.slab)
+    if (x_dtype == DBGSOM_F32) {
+        if (al16 && d % 4 == 0) DBGSOM_SEGSUM(float, 4); else DBGSOM_SEGSUM(float, 1);
+    } else {
+        if (al16 && d % 2 == 0) DBGSOM_SEGSUM(double, 2); else DBGSOM_SEGSUM(double, 1);
+    }
+#undef DBGSOM_SEGSUM
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)M), dim3(AT), 0, s, w.slab, di, Mi, w.count,
+                       w.chunk_pre, sums);
+    return launch_status("accumulate kernels");
+}
+
+}  // namespace dbgsom

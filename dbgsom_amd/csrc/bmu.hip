@@ -1,0 +1,360 @@
+// Best-matching-unit search on gfx950 (MI355X): float64 expanded-L2 distances on the f64 matrix
+// cores + per-sample arg-k-min with wavefront shuffles.
+//
+// Replaces BaseSom._get_winning_neurons (reference dbgsom/BaseSom.py:446-464), i.e. sklearn's
+// brute NearestNeighbors engine, whose arithmetic is float64 even for float32 samples:
+//     r_ij = (|x_i|^2 + (-2 <x_i,w_j>)) + |w_j|^2 ; clamp 0 ; argmin_j (ties -> lowest j) ; sqrt.
+//
+// Design (one 256-thread workgroup = 4 wavefronts of 64):
+//   * a workgroup owns BI=128 samples and sweeps all prototypes in chunks of BJ=128; the 2x2
+//     wavefronts each own a 64x64 (prototype x sample) block = 4x4 tiles of
+//     v_mfma_f64_16x16x4_f64, accumulated over the whole feature dimension in ONE chain per
+//     (sample, prototype) pair: the dot product is the sequential fma chain k = 0..d-1, the same
+//     order as oracle/bmu_chain.c, so winners and distances compare bit for bit.
+//   * prototypes are the A operand (tile rows), samples the B operand (tile columns): a lane then
+//     holds ONE sample (column = lane&15) against 4 prototypes per tile, so the running
+//     (min, argmin) lives in registers and never leaves the lane until the last chunk.
+//   * X (f32 or f64) and W (f64) tiles are staged global -> registers -> LDS (converted to f64 on
+//     the way) with the next tile's loads in flight under the current tile's MFMAs; LDS rows are
+//     padded to 18 doubles so the ds_read_b64 fragment reads are bank-conflict free.
+//   * epilogue: cross-lane merge with __shfl_xor (lanes l, l^16, l^32, l^48 share a sample),
+//     then the two wavefronts that share a sample merge through LDS.
+#include <math.h>
+
+#include "common.h"
+
+namespace dbgsom {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BI = 128;     // samples per workgroup
+constexpr int BJ = 128;     // prototypes per sweep chunk
+constexpr int KT = 16;      // feature depth of one LDS tile
+constexpr int LS = KT + 2;  // LDS row stride (doubles)
+constexpr int NT = 256;
+
+template <typename T>
+__device__ __forceinline__ void load8(const T *__restrict__ base, int64_t row, int64_t nrows,
+                                      int64_t ld, int k, int d, int vec_ok, T (&v)[8]) {
+    if (row < nrows && k < d) {
+        const T *p = base + row * ld + k;
+        if (vec_ok && k + 8 <= d) {
+            if constexpr (sizeof(T) == 4) {
+                const float4 a = *reinterpret_cast<const float4 *>(p);
+                const float4 b = *reinterpret_cast<const float4 *>(p + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+                v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double2 a = *reinterpret_cast<const double2 *>(p + 2 * e);
+                    v[2 * e] = a.x;
+                    v[2 * e + 1] = a.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (k + e < d) ? p[e] : T(0);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = T(0);
+    }
+}
+
+__device__ __forceinline__ bool lex_lt(double a, int ja, double b, int jb) {
+    return a < b || (a == b && ja < jb);
+}
+
+template <int K>
+struct Best {
+    double v[K];
+    int j[K];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int t = 0; t < K; ++t) { v[t] = INFINITY; j[t] = 0x7fffffff; }
+    }
+    // candidates arrive with ascending index inside one lane: strict '<' keeps the lowest index
+    __device__ __forceinline__ void push(double r, int idx) {
+        if constexpr (K == 1) {
+            if (r < v[0]) { v[0] = r; j[0] = idx; }
+        } else {
+            if (r < v[0]) { v[1] = v[0]; j[1] = j[0]; v[0] = r; j[0] = idx; }
+            else if (r < v[1]) { v[1] = r; j[1] = idx; }
+        }
+    }
+    // merge with another sorted list (lexicographic on (value, index))
+    __device__ __forceinline__ void merge(const double (&ov)[K], const int (&oj)[K]) {
+        if constexpr (K == 1) {
+            if (lex_lt(ov[0], oj[0], v[0], j[0])) { v[0] = ov[0]; j[0] = oj[0]; }
+        } else {
+            double n0, n1; int m0, m1;
+            if (lex_lt(ov[0], oj[0], v[0], j[0])) {
+                n0 = ov[0]; m0 = oj[0];
+                if (lex_lt(v[0], j[0], ov[1], oj[1])) { n1 = v[0]; m1 = j[0]; }
+                else { n1 = ov[1]; m1 = oj[1]; }
+            } else {
+                n0 = v[0]; m0 = j[0];
+                if (lex_lt(ov[0], oj[0], v[1], j[1])) { n1 = ov[0]; m1 = oj[0]; }
+                else { n1 = v[1]; m1 = j[1]; }
+            }
+            v[0] = n0; j[0] = m0; v[1] = n1; j[1] = m1;
+        }
+    }
+};
+
+template <typename XT, int K>
+__global__ __launch_bounds__(NT, 2) void bmu_kernel(
+    const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
+    const double *__restrict__ W, int M, const double *__restrict__ ww, int round_f32, int xvec,
+    int wvec, int64_t *__restrict__ idx_out, double *__restrict__ dist_out) {
+    __shared__ __attribute__((aligned(16))) double xs[BI * LS];
+    __shared__ __attribute__((aligned(16))) double wsm[BJ * LS];
+    __shared__ double yy_s[2][BJ];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;  // 2 x 2 wavefronts: sample half, prototype half
+    const int lr = lane & 15, lq = lane >> 4;
+    const int64_t i0 = (int64_t)blockIdx.x * BI;
+
+    double xi[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int64_t i = i0 + wi * 64 + it * 16 + lr;
+        xi[it] = (i < N) ? xx[i] : 0.0;
+    }
+    Best<K> best[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) best[it].init();
+
+    const int lrow = tid >> 1, lk = (tid & 1) * 8;  // staging: 2 threads per tile row, 8 values each
+    const int nkt = (d + KT - 1) / KT;
+    XT xr[8];
+    double wr[8];
+
+    int parity = 0;
+    for (int jc = 0; jc < M; jc += BJ, parity ^= 1) {
+        d4_t acc[4][4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+        load8<XT>(X, i0 + lrow, N, ldx, lk, d, xvec, xr);
+        load8<double>(W, (int64_t)jc + lrow, M, d, lk, d, wvec, wr);
+        if (tid < BJ) yy_s[parity][tid] = (jc + tid < M) ? ww[jc + tid] : 0.0;
+
+        for (int kt = 0; kt < nkt; ++kt) {
+            __syncthreads();  // every wavefront is done reading the previous tile
+            {
+                double *xd = &xs[lrow * LS + lk];
+                double *wd = &wsm[lrow * LS + lk];
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    *reinterpret_cast<double2 *>(xd + e) =
+                        double2{(double)xr[e], (double)xr[e + 1]};
+                    *reinterpret_cast<double2 *>(wd + e) = double2{wr[e], wr[e + 1]};
+                }
+            }
+            __syncthreads();
+            if (kt + 1 < nkt) {  // next tile's loads fly under this tile's MFMAs
+                const int kn = (kt + 1) * KT + lk;
+                load8<XT>(X, i0 + lrow, N, ldx, kn, d, xvec, xr);
+                load8<double>(W, (int64_t)jc + lrow, M, d, kn, d, wvec, wr);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KT / 4; ++ks) {
+                double a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a[t] = wsm[(wj * 64 + t * 16 + lr) * LS + ks * 4 + lq];
+                    b[t] = xs[(wi * 64 + t * 16 + lr) * LS + ks * 4 + lq];
+                }
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt], b[it],
+                                                                           acc[jt][it], 0, 0, 0);
+            }
+        }
+
+        // chunk epilogue: expanded L2 + running arg-k-min (prototype index ascends per lane)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jl = wj * 64 + jt * 16 + 4 * r + lq;
+                const int j = jc + jl;
+                const double y = yy_s[parity][jl];
+                if (j < M) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        double rv = (xi[it] + (-2.0 * acc[jt][it][r])) + y;
+                        if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;  // max(r, 0), NaN kept
+                        best[it].push(rv, j);
+                    }
+                }
+            }
+        }
+    }
+
+    // lanes l, l^16, l^32, l^48 hold the same sample against different prototypes
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) {
+            double ov[K];
+            int oj[K];
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                ov[t] = __shfl_xor(best[it].v[t], m, 64);
+                oj[t] = __shfl_xor(best[it].j[t], m, 64);
+            }
+            best[it].merge(ov, oj);
+        }
+    }
+
+    // the two wavefronts with the same `wi` hold the two prototype halves of the same samples
+    __syncthreads();
+    double *mv = xs;                             // [2][BI][K]
+    int *mj = reinterpret_cast<int *>(wsm);      // [2][BI][K]
+    if (lq == 0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int s = wi * 64 + it * 16 + lr;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                mv[(wj * BI + s) * K + t] = best[it].v[t];
+                mj[(wj * BI + s) * K + t] = best[it].j[t];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < BI) {
+        const int64_t i = i0 + tid;
+        if (i < N) {
+            Best<K> b;
+            double ov[K];
+            int oj[K];
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                b.v[t] = mv[(0 * BI + tid) * K + t];
+                b.j[t] = mj[(0 * BI + tid) * K + t];
+                ov[t] = mv[(1 * BI + tid) * K + t];
+                oj[t] = mj[(1 * BI + tid) * K + t];
+            }
+            b.merge(ov, oj);
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                double dv = sqrt(b.v[t]);
+                if (round_f32) dv = (double)(float)dv;
+                idx_out[i * K + t] = (b.j[t] == 0x7fffffff) ? (int64_t)-1 : (int64_t)b.j[t];
+                dist_out[i * K + t] = dv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// squared row norms, sequential fma chain per row (same order as the oracle); rows are staged
+// through LDS so the global reads stay coalesced while each thread walks its own row.
+// ---------------------------------------------------------------------------------------------
+constexpr int NR = 128;  // rows per workgroup (= threads)
+constexpr int NK = 32;   // features per staged tile
+
+template <typename T>
+__global__ __launch_bounds__(NR) void row_sqnorms_kernel(const T *__restrict__ A, int64_t rows,
+                                                         int d, int64_t ld,
+                                                         double *__restrict__ out) {
+    __shared__ double tile[NR][NK + 1];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * NR;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < d; k0 += NK) {
+        __syncthreads();
+        // 128 x 32 elements, 32 consecutive features per row-group of 32 threads
+        const int c = tid & 31, rg = tid >> 5;
+#pragma unroll 4
+        for (int p = 0; p < NR / 4; ++p) {
+            const int r = p * 4 + rg;
+            const int64_t row = r0 + r;
+            const int k = k0 + c;
+            tile[r][c] = (row < rows && k < d) ? (double)A[row * ld + k] : 0.0;
+        }
+        __syncthreads();
+        const int kmax = min(NK, d - k0);
+        for (int kk = 0; kk < kmax; ++kk) {
+            const double v = tile[tid][kk];
+            acc = fma(v, v, acc);
+        }
+    }
+    if (r0 + tid < rows) out[r0 + tid] = acc;
+}
+
+__global__ void exp_similarity_kernel(const double *__restrict__ dist, int64_t N, double gamma,
+                                      double *__restrict__ kw) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const double dd = dist[i];
+        kw[i] = 1.0 - sqrt(1.0 - exp(-gamma * (dd * dd)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+int launch_row_sqnorms(const void *A, int dtype, int64_t rows, int64_t d, int64_t ld, double *out,
+                       hipStream_t s) {
+    DBGSOM_REQUIRE(dtype == DBGSOM_F32 || dtype == DBGSOM_F64, "dtype must be DBGSOM_F32/F64");
+    DBGSOM_REQUIRE(rows >= 0 && d >= 1 && ld >= d && d <= 0x7fffffff, "bad shape");
+    if (rows == 0) return DBGSOM_OK;
+    DBGSOM_REQUIRE(A && out, "null pointer");
+    const int64_t nb = (rows + NR - 1) / NR;
+    DBGSOM_REQUIRE(nb <= 0x7fffffff, "too many rows");
+    if (dtype == DBGSOM_F32)
+        hipLaunchKernelGGL(row_sqnorms_kernel<float>, dim3((unsigned)nb), dim3(NR), 0, s,
+                           (const float *)A, rows, (int)d, ld, out);
+    else
+        hipLaunchKernelGGL(row_sqnorms_kernel<double>, dim3((unsigned)nb), dim3(NR), 0, s,
+                           (const double *)A, rows, (int)d, ld, out);
+    return launch_status("row_sqnorms_kernel");
+}
+
+int launch_bmu(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx, const double *xx,
+               const double *W, int64_t M, const double *ww, int k, int round_f32, int64_t *idx,
+               double *dist, hipStream_t s) {
+    DBGSOM_REQUIRE(x_dtype == DBGSOM_F32 || x_dtype == DBGSOM_F64, "x_dtype must be DBGSOM_F32/F64");
+    DBGSOM_REQUIRE(k == 1 || k == 2, "k must be 1 or 2");
+    DBGSOM_REQUIRE(N >= 0 && d >= 1 && ldx >= d && d <= 0x7fffffff, "bad sample shape");
+    DBGSOM_REQUIRE(M >= k && M <= 0x7fffff00, "need k <= M < 2^31");
+    if (N == 0) return DBGSOM_OK;
+    DBGSOM_REQUIRE(X && xx && W && ww && idx && dist, "null pointer");
+    const int64_t nb = (N + BI - 1) / BI;
+    DBGSOM_REQUIRE(nb <= 0x7fffffff, "too many samples for one launch");
+    const size_t xe = (x_dtype == DBGSOM_F32) ? 4 : 8;
+    const int xvec = is_aligned(X, 16) && ((ldx * xe) % 16 == 0);
+    const int wvec = is_aligned(W, 16) && ((d * 8) % 16 == 0);
+    dim3 grid((unsigned)nb), block(NT);
+#define DBGSOM_BMU_LAUNCH(XT, KK)                                                              \
+    hipLaunchKernelGGL((bmu_kernel<XT, KK>), grid, block, 0, s, (const XT *)X, N, (int)d, ldx, \
+                       xx, W, (int)M, ww, round_f32, xvec, wvec, idx, dist)
+    if (x_dtype == DBGSOM_F32) {
+        if (k == 1) DBGSOM_BMU_LAUNCH(float, 1); else DBGSOM_BMU_LAUNCH(float, 2);
+    } else {
+        if (k == 1) DBGSOM_BMU_LAUNCH(double, 1); else DBGSOM_BMU_LAUNCH(double, 2);
+    }
+#undef DBGSOM_BMU_LAUNCH
+    return launch_status("bmu_kernel");
+}
+
+int launch_exp_similarity(const double *dist, int64_t N, double gamma, double *kw, hipStream_t s) {
+    DBGSOM_REQUIRE(N >= 0, "bad N");
+    if (N == 0) return DBGSOM_OK;
+    DBGSOM_REQUIRE(dist && kw, "null pointer");
+    const int64_t nb = (N + 255) / 256;
+    hipLaunchKernelGGL(exp_similarity_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256),
+                       0, s, dist, N, gamma, kw);
+    return launch_status("exp_similarity_kernel");
+}
+
+}  // namespace dbgsom

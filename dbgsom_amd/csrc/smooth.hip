@@ -1,0 +1,213 @@
+// Neighbourhood-weighted batch update on gfx950 (float64 throughout).
+//
+// Replaces steps 3-5 of BaseSom._update_weights (reference dbgsom/BaseSom.py:506-522) and
+// _calculate_gaussian_neighborhood (:525-531):
+//     c_j  = S_j / K_j  (rows placed per `layout`; COMPACT reproduces quirk Q1, :1045,1053)
+//     g_ij = exp(-(hop_ij^2 / (2 sigma^2))) * a_j
+//     W'_i = sum_j g_ij c_j / sum_j g_ij ;   change_total = sum_i |W_i - W'_i|_2
+// The reference materialises an (M, M, d) float64 temporary for the same sum; here it is one
+// M x M x d float64 GEMM (2 M^2 d flops, < 0.2 % of the BMU work at M ~ 1000), LDS-tiled.
+#include <math.h>
+
+#include "common.h"
+
+namespace dbgsom {
+
+struct SmoothWs {
+    double *C;      // M x d   Voronoi centres in the requested layout
+    double *G;      // M x M   h * a^T
+    double *den;    // M
+    double *rowchg; // M
+    int32_t *rank;  // M       rank among non-empty neurons
+};
+
+static size_t carve_smooth(SmoothWs *w, char *base, int64_t M, int64_t d) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t oC = take((size_t)M * d * 8), oG = take((size_t)M * M * 8);
+    const size_t oD = take((size_t)M * 8), oR = take((size_t)M * 8), oK = take((size_t)M * 4);
+    if (w) {
+        w->C = (double *)(base + oC); w->G = (double *)(base + oG);
+        w->den = (double *)(base + oD); w->rowchg = (double *)(base + oR);
+        w->rank = (int32_t *)(base + oK);
+    }
+    return off;
+}
+
+size_t smooth_workspace_bytes(int64_t M, int64_t d) {
+    if (M < 1 || d < 1) return 0;
+    return carve_smooth(nullptr, nullptr, M, d);
+}
+
+// rank[j] = number of non-empty neurons before j (one workgroup, ordered)
+__global__ __launch_bounds__(1024) void rank_kernel(const double *__restrict__ a, int M,
+                                                    int32_t *__restrict__ rank) {
+    __shared__ int32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (M + 1023) / 1024;
+    const int lo = t * per, hi = min(M, lo + per);
+    int32_t c = 0;
+    for (int j = lo; j < hi; ++j) c += (a[j] > 0.0);
+    part[t] = c;
+    __syncthreads();
+    if (t == 0) {
+        int32_t run = 0;
+        for (int u = 0; u < 1024; ++u) { const int32_t v = part[u]; part[u] = run; run += v; }
+    }
+    __syncthreads();
+    c = part[t];
+    for (int j = lo; j < hi; ++j) { rank[j] = c; c += (a[j] > 0.0); }
+}
+
+// C[dst(j), :] = S[j, :] / K[j] for non-empty j; C was zero-filled beforehand
+__global__ void centres_kernel(const double *__restrict__ S, const double *__restrict__ K,
+                               const double *__restrict__ a, const int32_t *__restrict__ rank,
+                               int M, int d, int layout, double *__restrict__ C) {
+    const int j = blockIdx.x;
+    if (!(a[j] > 0.0)) return;
+    const int dst = (layout == DBGSOM_CENTRES_COMPACT) ? rank[j] : j;
+    const double k = K[j];
+    for (int c = threadIdx.x; c < d; c += blockDim.x)
+        C[(size_t)dst * d + c] = S[(size_t)j * d + c] / k;
+}
+
+// G[i, j] = exp(-(hop^2 / (2 sigma^2))) * a_j ; den[i] = sum_j G[i, j] (fixed tree order)
+__global__ __launch_bounds__(256) void neighbourhood_kernel(const float *__restrict__ hop,
+                                                            const double *__restrict__ a, int M,
+                                                            double two_sigma_sq,
+                                                            double *__restrict__ G,
+                                                            double *__restrict__ den) {
+    __shared__ double red[256];
+    const int i = blockIdx.x, t = threadIdx.x;
+    double s = 0.0;
+    for (int j = t; j < M; j += 256) {
+        const double h = (double)hop[(size_t)i * M + j];
+        const double g = exp(-((h * h) / two_sigma_sq)) * a[j];
+        G[(size_t)i * M + j] = g;
+        s += g;
+    }
+    red[t] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) den[i] = red[0];
+}
+
+// W'[i, c] = (sum_j G[i, j] C[j, c]) / den[i]   -- 64 x 64 tile per workgroup, 4 x 4 per thread,
+// j ascending inside one accumulator (sequential like the reference's np.sum over axis 1)
+constexpr int GT = 64, GK = 16;
+__global__ __launch_bounds__(256) void smooth_gemm_kernel(const double *__restrict__ G,
+                                                          const double *__restrict__ C,
+                                                          const double *__restrict__ den, int M,
+                                                          int d, double *__restrict__ Wn) {
+    __shared__ double gs[GT][GK + 1];
+    __shared__ double cs[GK][GT + 1];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int i0 = blockIdx.y * GT, c0 = blockIdx.x * GT;
+    double acc[4][4] = {};
+    for (int j0 = 0; j0 < M; j0 += GK) {
+        __syncthreads();
+        for (int e = t; e < GT * GK; e += 256) {
+            const int r = e / GK, k = e % GK;  // G tile: 64 rows x 16 j
+            const int gi = i0 + r, gj = j0 + k;
+            gs[r][k] = (gi < M && gj < M) ? G[(size_t)gi * M + gj] : 0.0;
+            const int kr = e / GT, cc = e % GT;  // C tile: 16 j x 64 cols
+            const int cj = j0 + kr, col = c0 + cc;
+            cs[kr][cc] = (cj < M && col < d) ? C[(size_t)cj * d + col] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GK; ++k) {
+            double gv[4], cv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { gv[u] = gs[ty * 4 + u][k]; cv[u] = cs[k][tx * 4 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += gv[u] * cv[v];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + ty * 4 + u;
+        if (i >= M) continue;
+        const double dn = den[i];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int c = c0 + tx * 4 + v;
+            if (c < d) Wn[(size_t)i * d + c] = acc[u][v] / dn;
+        }
+    }
+}
+
+// rowchg[i] = |W_i - W'_i|_2
+__global__ __launch_bounds__(256) void rowchange_kernel(const double *__restrict__ Wo,
+                                                        const double *__restrict__ Wn, int d,
+                                                        double *__restrict__ rowchg) {
+    __shared__ double red[256];
+    const int i = blockIdx.x, t = threadIdx.x;
+    double s = 0.0;
+    for (int c = t; c < d; c += 256) {
+        const double df = Wo[(size_t)i * d + c] - Wn[(size_t)i * d + c];
+        s += df * df;
+    }
+    red[t] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) rowchg[i] = sqrt(red[0]);
+}
+
+__global__ __launch_bounds__(1024) void total_kernel(const double *__restrict__ v, int M,
+                                                     double *__restrict__ out) {
+    __shared__ double red[1024];
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int j = t; j < M; j += 1024) s += v[j];
+    red[t] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) out[0] = red[0];
+}
+
+int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, double sigma,
+                  int layout, const double *W_old, double *W_new, double *change_total, void *ws,
+                  size_t ws_bytes, hipStream_t s) {
+    DBGSOM_REQUIRE(M >= 1 && M <= 0x7fff && d >= 1 && d <= 0x7ffffff0, "bad shape");
+    DBGSOM_REQUIRE(layout == DBGSOM_CENTRES_COMPACT || layout == DBGSOM_CENTRES_ALIGNED,
+                   "layout must be DBGSOM_CENTRES_COMPACT/ALIGNED");
+    DBGSOM_REQUIRE(sums && hop && W_old && W_new && change_total && ws, "null pointer");
+    DBGSOM_REQUIRE(W_old != W_new, "W_new must not alias W_old");
+    DBGSOM_REQUIRE(is_aligned(ws, 256), "workspace must be 256-byte aligned");
+    DBGSOM_REQUIRE(sigma > 0.0, "sigma must be positive");
+    if (ws_bytes < smooth_workspace_bytes(M, d)) {
+        set_error("dbgsom_smooth: workspace too small (%zu < %zu)", ws_bytes,
+                  smooth_workspace_bytes(M, d));
+        return DBGSOM_ENOMEM;
+    }
+    SmoothWs w;
+    carve_smooth(&w, (char *)ws, M, d);
+    const int Mi = (int)M, di = (int)d;
+    const double *S = sums, *K = sums + (size_t)M * d, *a = K + M;
+    DBGSOM_HIP_CHECK(hipMemsetAsync(w.C, 0, (size_t)M * d * 8, s));
+    hipLaunchKernelGGL(rank_kernel, dim3(1), dim3(1024), 0, s, a, Mi, w.rank);
+    hipLaunchKernelGGL(centres_kernel, dim3((unsigned)M), dim3(256), 0, s, S, K, a, w.rank, Mi, di,
+                       layout, w.C);
+    hipLaunchKernelGGL(neighbourhood_kernel, dim3((unsigned)M), dim3(256), 0, s, hop, a, Mi,
+                       2.0 * (sigma * sigma), w.G, w.den);
+    dim3 grid((unsigned)((d + GT - 1) / GT), (unsigned)((M + GT - 1) / GT));
+    hipLaunchKernelGGL(smooth_gemm_kernel, grid, dim3(256), 0, s, w.G, w.C, w.den, Mi, di, W_new);
+    hipLaunchKernelGGL(rowchange_kernel, dim3((unsigned)M), dim3(256), 0, s, W_old, W_new, di,
+                       w.rowchg);
+    hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1024), 0, s, w.rowchg, Mi, change_total);
+    return launch_status("smooth kernels");
+}
+
+}  // namespace dbgsom

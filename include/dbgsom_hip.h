@@ -1,0 +1,150 @@
+/*
+ * dbgsom_hip.h -- C ABI of the MI355X (gfx950) batch-SOM hot path.
+ *
+ * Drop-in boundary for the per-epoch hot path of SandroMartens/DBGSOM.  The reference has
+ * no FFI seam of its own: the path sits behind four private methods of `BaseSom` and two
+ * numba functions (dbgsom/BaseSom.py).  Each entry point below names the reference
+ * interface it replaces (file:line under the reference tree).  INTEGRATION.md shows the
+ * ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every function returns 0 on success, a negative DBGSOM_E* code on failure;
+ *     dbgsom_last_error() returns the message of the calling thread's last failure.
+ *     HIP errors never cross the ABI as exceptions.
+ *   - "dev" pointers are device (HBM) addresses, "host" pointers are host addresses.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Device-level
+ *     calls only ENQUEUE work on `stream`; the caller synchronises.  Context-level calls
+ *     (dbgsom_ctx_*) are blocking.
+ *   - matrices are row-major; `ld*` is the row stride in ELEMENTS.
+ *   - handles are not thread-safe; calls are blocking from one host thread per context.
+ */
+#ifndef DBGSOM_HIP_H
+#define DBGSOM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DBGSOM_ABI_VERSION 1
+
+/* sample storage types (the reference accepts float64 and float32 input: SomVQ.py:121-124) */
+#define DBGSOM_F32 0
+#define DBGSOM_F64 1
+
+/* layout of the Voronoi-centre rows fed to the smoothing step */
+#define DBGSOM_CENTRES_COMPACT 0 /* reference behaviour: BaseSom.py:1045,1053 (row = rank among non-empty neurons) */
+#define DBGSOM_CENTRES_ALIGNED 1 /* row = neuron id (the mathematically intended form) */
+
+#define DBGSOM_OK 0
+#define DBGSOM_EINVAL (-1)   /* bad argument (shape, dtype, null pointer, k, alignment) */
+#define DBGSOM_EHIP (-2)     /* a HIP runtime call failed; see dbgsom_last_error() */
+#define DBGSOM_ENOMEM (-3)   /* workspace too small / allocation failed */
+#define DBGSOM_ESTATE (-4)   /* context used out of order (e.g. epoch before load) */
+#define DBGSOM_ERANGE (-5)   /* a winner index outside [0, M) was met */
+
+/* prototype-count limit of the accumulate step (per-block LDS histogram) */
+#define DBGSOM_MAX_PROTOTYPES 16000
+
+int dbgsom_abi_version(void);
+const char *dbgsom_last_error(void);
+/* number of visible HIP devices (0 and DBGSOM_OK when none: the caller decides to fail) */
+int dbgsom_device_count(int *count);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-level entry points (raw HBM pointers + stream).  One call = one step of the path.
+ * ------------------------------------------------------------------------------------------ */
+
+/* out[r] = sum_k A[r,k]^2 in float64, sequential fma chain over k.
+ * Replaces the row-norm pre-pass of sklearn's brute engines that BaseSom.py:455-457 calls
+ * (`row_norms(..., squared=True)`).  Run once per resident X, once per epoch for W. */
+int dbgsom_row_sqnorms(const void *A_dev, int dtype, int64_t rows, int64_t d, int64_t ld,
+                       double *out_dev, void *stream);
+
+/* Best-matching-unit search: BaseSom._get_winning_neurons(data, n_bmu)  BaseSom.py:446-464.
+ *   r_ij = (|x_i|^2 + (-2 <x_i,w_j>)) + |w_j|^2 in float64, clamp at 0, arg-k-min over j with
+ *   ties to the lowest j, dist = sqrt(r).  k in {1,2}.
+ *   X: N x d (x_dtype), xx: N squared norms; W: M x d float64 contiguous, ww: M squared norms.
+ *   idx: N x k int64, dist: N x k float64 (ascending by (r, j)).
+ *   round_f32 != 0 rounds the returned distances through float32 (what the reference's engine
+ *   does when samples AND prototypes are float32, i.e. epoch 0 of a float32 fit). */
+int dbgsom_bmu(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+               const double *xx_dev, const double *W_dev, int64_t M, const double *ww_dev, int k,
+               int round_f32, int64_t *idx_dev, double *dist_dev, void *stream);
+
+/* Sample kernel: BaseSom._calculate_exp_similarity(distances)  BaseSom.py:533-538.
+ *   kw_i = 1 - sqrt(1 - exp(-gamma * dist_i^2)),  gamma = 1 / total_variance. */
+int dbgsom_exp_similarity(const double *dist_dev, int64_t N, double gamma, double *kw_dev,
+                          void *stream);
+
+/* Per-neuron sums of one epoch, id-indexed, deterministic (stable counting sort by winner +
+ * ordered segmented reduction; no floating-point atomics):
+ *   S_j = sum_{i: win_i=j} kw_i x_i   numba_voronoi_set_centers numerator  BaseSom.py:1028-1055
+ *   K_j = sum kw_i                     its denominator
+ *   a_j = |{i}|                        neuron_activations                   BaseSom.py:500-503
+ *   E_j = sum dist_i                   numba_quantization_error             BaseSom.py:1058-1073
+ * sums_dev holds M*(d+3) float64:  [ S (M*d) | K (M) | a (M) | E (M) ]  -- the buffer a
+ * sample-sharded multi-GPU run all-reduces (one collective per epoch).
+ * status_dev (int32[1], may be NULL) is set non-zero when a winner is outside [0,M) (that
+ * sample is skipped). */
+size_t dbgsom_accumulate_workspace_bytes(int64_t N, int64_t d, int64_t M);
+int dbgsom_accumulate(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                      const int64_t *idx_dev, const double *kw_dev, const double *dist_dev,
+                      int64_t M, double *sums_dev, int32_t *status_dev, void *workspace_dev,
+                      size_t workspace_bytes, void *stream);
+
+/* Neighbourhood-weighted batch update: steps 3-5 of BaseSom._update_weights
+ * BaseSom.py:506-522 with _calculate_gaussian_neighborhood BaseSom.py:525-531.
+ *   c_j = S_j / K_j placed per `layout`;  h = exp(-(hop^2 / (2 sigma^2)));
+ *   W'_i = sum_j h_ij a_j c_j / sum_j h_ij a_j;   change_total = sum_i |W_i - W'_i|_2.
+ * hop: M x M float32 lattice hop counts (+inf when disconnected).  W_new may not alias W_old.
+ * change_total_dev: one float64 on the device. */
+size_t dbgsom_smooth_workspace_bytes(int64_t M, int64_t d);
+int dbgsom_smooth(const double *sums_dev, int64_t M, int64_t d, const float *hop_dev,
+                  double sigma, int layout, const double *W_old_dev, double *W_new_dev,
+                  double *change_total_dev, void *workspace_dev, size_t workspace_bytes,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Context-level entry points (host pointers; the library owns the device memory).
+ * This is the seam a NumPy caller such as the reference binds with ctypes: X is uploaded once
+ * and stays resident in HBM across epochs; every result is written into caller-allocated,
+ * C-contiguous host arrays; no host pointer is retained after a call returns.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dbgsom_ctx dbgsom_ctx;
+
+int dbgsom_ctx_create(int device, dbgsom_ctx **out);
+int dbgsom_ctx_destroy(dbgsom_ctx *ctx);
+
+/* Upload the training samples once (BaseSom.fit's `X`, BaseSom.py:88-114). */
+int dbgsom_ctx_load(dbgsom_ctx *ctx, const void *X_host, int x_dtype, int64_t N, int64_t d);
+
+/* Lattice hop distances, M x M float64 as nx.floyd_warshall_numpy returns them
+ * (BaseSom.py:367,401).  Call again whenever neurons were added. */
+int dbgsom_ctx_set_topology(dbgsom_ctx *ctx, const double *hop_host, int64_t M);
+
+/* _get_winning_neurons on the resident samples.  BaseSom.py:446-464. */
+int dbgsom_ctx_bmu(dbgsom_ctx *ctx, const double *W_host, int64_t M, int k, int round_f32,
+                   int64_t *idx_host, double *dist_host);
+
+/* _get_winning_neurons on other samples (predict, SomVQ.py:130-148). */
+int dbgsom_ctx_bmu_query(dbgsom_ctx *ctx, const void *Xq_host, int x_dtype, int64_t Nq,
+                         int64_t d, const double *W_host, int64_t M, int k, int round_f32,
+                         int64_t *idx_host, double *dist_host);
+
+/* One pass of the body of BaseSom._grow_som (BaseSom.py:403-407):
+ * BMU -> sample kernel -> weighted sums -> smoothing -> convergence norm -> per-neuron error.
+ * Outputs (host): W_new M x d, change_total[1], errors[M], activations[M];
+ * idx_host / dist_host (N each) may be NULL when the caller does not need the assignments. */
+int dbgsom_ctx_epoch(dbgsom_ctx *ctx, const double *W_host, int64_t M, int round_f32,
+                     double gamma, double sigma, int layout, double *W_new_host,
+                     double *change_total_host, double *errors_host, double *activations_host,
+                     int64_t *idx_host, double *dist_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBGSOM_HIP_H */

@@ -292,15 +292,28 @@ def epoch(X, W, hop, sigma, total_variance, layout="compact", bmu="chain", smoot
     return EpochOut(Wn, change_total(W64, Wn), E, a, win, dist, kw, C)
 
 
-class OracleBackend:
+def exp_similarity_gamma(distances, gamma):
+    """`exp_similarity` with gamma already formed (the backends receive gamma, not the variance)."""
+    d = np.asarray(distances, dtype=np.float64)
+    return 1 - np.sqrt(1 - np.exp(-float(gamma) * np.square(d)))
+
+
+def _backend_base():
+    from dbgsom_amd.backend import HotPathBackend
+
+    return HotPathBackend
+
+
+class OracleBackend(_backend_base()):
     """CPU stand-in with the same interface as ``dbgsom_amd.backend.HipBackend`` so that the
-    host logic (growth, sigma schedule, estimator plumbing) can be tested without a GPU.
-    TESTS ONLY: the product's default backend is the HIP one and raises when it cannot load."""
+    host logic (growth, sigma schedule, estimator plumbing, the sharded all-reduce) can be tested
+    without a GPU.  TESTS ONLY: the product's default backend is the HIP one and raises when it
+    cannot load; nothing under ``dbgsom_amd/`` imports this class."""
 
     name = "oracle"
 
     def __init__(self, bmu: str = "chain"):
-        self._bmu = bmu
+        self._fn = {"chain": bmu_chain, "blas": bmu_blas, "sklearn": bmu_sklearn}[bmu]
         self._X = None
 
     def load(self, X):
@@ -313,22 +326,35 @@ class OracleBackend:
 
     def bmu(self, W, k=1, X=None):
         Xq = self._X if X is None else np.ascontiguousarray(X)
-        fn = {"chain": bmu_chain, "blas": bmu_blas, "sklearn": bmu_sklearn}[self._bmu]
-        return fn(Xq, W, k)
+        return self._fn(Xq, np.asarray(W), k)
 
-    def exp_similarity(self, distances, total_variance):
-        return exp_similarity(distances, total_variance)
+    def exp_similarity(self, distances, gamma):
+        return exp_similarity_gamma(distances, gamma)
 
-    def update(self, W, hop, sigma, sample_weights, winners, distances, layout="compact"):
-        M = W.shape[0]
-        S, K, a, E = accumulate(self._X, winners, sample_weights, distances, M)
+    def _pack(self, S, K, a, E):
+        import torch
+
+        return torch.from_numpy(np.concatenate([S.reshape(-1), K, a, E]))
+
+    def _local_sums(self, W, gamma, want_assignments):
+        dist, win = self._fn(self._X, np.asarray(W), 1)
+        kw = exp_similarity_gamma(dist, gamma)
+        sums = self._pack(*accumulate(self._X, win, kw, dist, np.asarray(W).shape[0]))
+        return sums, (win if want_assignments else None), (dist if want_assignments else None)
+
+    def _sums_from(self, W, sample_weights, winners, distances):
+        return self._pack(*accumulate(self._X, winners, sample_weights, distances,
+                                      np.asarray(W).shape[0]))
+
+    def _smooth(self, sums, W, hop, sigma, layout):
+        W64 = np.asarray(W, dtype=np.float64)
+        M, d = W64.shape
+        v = sums.numpy()
+        S, K, a, E = v[:M * d].reshape(M, d), v[M * d:M * d + M], v[M * d + M:M * d + 2 * M], \
+            v[M * d + 2 * M:]
         C = voronoi_centers(S, K, a, layout)
         Wn = smooth_matmul(gaussian_neighborhood(hop, sigma), a, C)
-        return Wn, change_total(np.asarray(W, dtype=np.float64), Wn), E, a
-
-    def epoch(self, W, hop, sigma, total_variance, layout="compact", want_assignments=False):
-        out = epoch(self._X, W, hop, sigma, total_variance, layout, self._bmu)
-        return out
+        return Wn, change_total(W64, Wn), E.copy(), a.copy()
 
     def release(self):
         self._X = None

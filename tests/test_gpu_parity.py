@@ -1,0 +1,286 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on identical inputs.
+Run on the MI355X box with `pytest -m gpu`."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from dbgsom_amd.backend import HipBackend
+
+    return HipBackend()
+
+
+@pytest.fixture(scope="module")
+def o():
+    from oracle import som_oracle
+
+    return som_oracle
+
+
+def _rand(N, d, M, dt, seed):
+    rng = np.random.default_rng(seed)
+    X = (rng.normal(size=(N, d)) * rng.uniform(0.5, 3.0, size=d)).astype(dt)
+    W = rng.normal(size=(M, d)) * 1.5
+    return X, W
+
+
+SHAPES = [
+    # N, d, M, dtype
+    (1, 1, 1, np.float32),
+    (5, 3, 2, np.float64),
+    (127, 15, 7, np.float32),
+    (128, 16, 128, np.float32),
+    (129, 17, 129, np.float64),
+    (1000, 64, 25, np.float64),
+    (777, 100, 300, np.float32),
+    (2049, 130, 257, np.float32),
+    (513, 784, 140, np.float32),
+    (300, 33, 1030, np.float64),
+]
+
+
+@pytest.mark.parametrize("N,d,M,dt", SHAPES)
+@pytest.mark.parametrize("k", [1, 2])
+def test_bmu_bit_exact(hip, o, N, d, M, dt, k):
+    if M < k:
+        pytest.skip("k > M")
+    X, W = _rand(N, d, M, dt, seed=N * 31 + d)
+    hip.load(X)
+    dist, idx = hip.bmu(W, k)
+    rd, ri = o.bmu_chain(X, W, k)
+    assert np.array_equal(idx, ri)          # BMU indices: bit-exact
+    assert np.array_equal(dist, rd)         # same fma chain + correctly rounded sqrt: bit-exact
+    # and against the BLAS statement (summation order differs): indices equal, distances close
+    bd, bi = o.bmu_blas(X, W, k)
+    assert np.array_equal(idx, bi)
+    np.testing.assert_allclose(dist ** 2, bd ** 2, rtol=1e-10, atol=1e-9)
+
+
+def test_bmu_query_path_and_f32_pair_rounding(hip, o):
+    X, W = _rand(400, 20, 9, np.float32, 5)
+    hip.load(X)
+    W32 = W.astype(np.float32)
+    dist, idx = hip.bmu(W32, 1)
+    rd, ri = o.bmu_chain(X, W32, 1)
+    assert np.array_equal(idx, ri) and np.array_equal(dist, rd)
+    assert np.array_equal(dist, dist.astype(np.float32).astype(np.float64))
+    Xq, _ = _rand(77, 20, 9, np.float64, 6)
+    dq, iq = hip.bmu(W, 2, X=Xq)
+    rq, rqi = o.bmu_chain(Xq, W, 2)
+    assert np.array_equal(iq, rqi) and np.array_equal(dq, rq)
+
+
+def test_ties_lowest_index(hip):
+    X = np.array([[1.0, 2.0, 3.0], [0.0, 0.0, 0.0], [2.0, 2.0, 2.0]], dtype=np.float64)
+    W = np.array([[5.0, 5.0, 5.0], [1.0, 2.0, 3.0], [1.0, 2.0, 3.0], [0.0, 0.0, 0.0]])
+    hip.load(X)
+    d, i = hip.bmu(W, 2)
+    assert i[:2].tolist() == [[1, 2], [3, 1]]
+    assert d[0].tolist() == [0.0, 0.0]
+    # many duplicated prototypes spread over tiles / lanes / wavefronts
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 5, size=(6, 12)).astype(np.float64)
+    W2 = np.tile(base, (60, 1))  # 360 prototypes, each row repeated 60 times
+    X2 = rng.integers(0, 5, size=(500, 12)).astype(np.float64)
+    hip.load(X2)
+    d2, i2 = hip.bmu(W2, 2)
+    assert (i2[:, 0] < 6).all()                 # lowest copy wins
+    assert (i2[:, 1] == i2[:, 0] + 6).all()     # second = next copy of the same row
+
+
+@pytest.mark.parametrize("name", gi.FIT_CASES)
+def test_golden_epochs(hip, o, name):
+    """Every recorded epoch of the reference's own fits: winners bit-exact, the rest within
+    float64 noise (north_star: weights within 1e-5 rel)."""
+    g = gi.load(name)
+    X, _ = gi.case_X(name)
+    hip.load(X)
+    for e in [int(v) for v in g["epochs_full"]]:
+        W = g[f"e{e}_weights_in"]
+        hop = g[f"e{e}_hop_distance"]
+        gamma = float(X.dtype.type(g[f"e{e}_total_variance"]) ** -1)
+        res = hip.epoch(W, hop, float(g[f"e{e}_sigma"]), gamma, "compact", True)
+        assert np.array_equal(res.winners, g[f"e{e}_winners"]), (name, e)
+        xn = float(np.max(np.einsum("ij,ij->i", X, X, dtype=np.float64)))
+        np.testing.assert_allclose(res.distances ** 2, g[f"e{e}_distances"] ** 2,
+                                   rtol=1e-7 if W.dtype == np.float32 else 1e-9, atol=1e-12 * xn)
+        assert np.array_equal(res.activations, g[f"e{e}_activations"])
+        np.testing.assert_allclose(res.errors, g[f"e{e}_errors"], rtol=1e-9, atol=1e-6)
+        np.testing.assert_allclose(res.new_weights, g[f"e{e}_weights_out"], rtol=1e-7, atol=1e-9,
+                                   equal_nan=True)
+        # against the oracle on the same inputs: tight
+        oo = o.epoch(X, W, hop, float(g[f"e{e}_sigma"]), X.dtype.type(g[f"e{e}_total_variance"]),
+                     "compact", "chain")
+        assert np.array_equal(res.winners, oo.winners)
+        assert np.array_equal(res.distances, oo.distances)
+        np.testing.assert_allclose(res.new_weights, oo.new_weights, rtol=1e-11, atol=1e-12,
+                                   equal_nan=True)
+        np.testing.assert_allclose(res.errors, oo.errors, rtol=1e-12)
+        np.testing.assert_allclose(res.change_total, oo.change_total, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", gi.FROZEN_CASES)
+def test_golden_frozen(hip, o, name):
+    g = gi.load(name)
+    X, _ = gi.case_X(name)
+    W, rows, cols = gi.frozen_W(name, X)
+    hop = gi.lattice_hops(rows, cols)
+    hip.load(X)
+    gamma = float(X.dtype.type(g["total_variance"]) ** -1)
+    res = hip.epoch(W, hop, float(g["sigma"]), gamma, "compact", True)
+    assert np.array_equal(res.winners, g["winners"])
+    assert np.array_equal(res.activations, g["activations"])
+    np.testing.assert_allclose(res.errors, g["errors"], rtol=1e-9, atol=5e-6)
+    np.testing.assert_allclose(res.new_weights[:8], g["weights_out_head"], rtol=1e-5)  # north_star
+    np.testing.assert_allclose(res.new_weights[:8], g["weights_out_head"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(res.new_weights.sum(axis=1), g["weights_out_sum_rows"], rtol=1e-7,
+                               atol=1e-8)
+    d2, i2 = hip.bmu(W, 2)
+    assert np.array_equal(i2, g["bmu2_idx"])
+
+
+def test_accumulate_and_smooth_vs_oracle_with_dead_neurons(hip, o):
+    rng = np.random.default_rng(9)
+    N, d, M = 5000, 37, 50
+    X = rng.normal(size=(N, d)).astype(np.float32)
+    W = rng.normal(size=(M, d))
+    W[[3, 4, 17, 49]] += 50.0  # never win -> dead neurons (quirk Q1 territory)
+    hip.load(X)
+    dist, win = hip.bmu(W, 1)
+    gamma = 1.0 / float(np.var(X, axis=0).sum())
+    kw = hip.exp_similarity(dist, gamma)
+    np.testing.assert_allclose(kw, o.exp_similarity_gamma(dist, gamma), rtol=1e-13, atol=1e-16)
+    rows, cols = 5, 10
+    hop = gi.lattice_hops(rows, cols)
+    for layout in ("compact", "aligned"):
+        Wn, chg, E, a = hip.update(W, hop, 1.3, kw, win, dist, layout)
+        S, K, a_o, E_o = o.accumulate(X, win, kw, dist, M)
+        C = o.voronoi_centers(S, K, a_o, layout)
+        Wo = o.smooth_matmul(o.gaussian_neighborhood(hop, 1.3), a_o, C)
+        assert (a_o == 0).sum() >= 4
+        assert np.array_equal(a, a_o)
+        np.testing.assert_allclose(E, E_o, rtol=1e-12)
+        np.testing.assert_allclose(Wn, Wo, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(chg, o.change_total(W, Wo), rtol=1e-10)
+
+
+def test_disconnected_lattice_and_nan_rows(hip, o):
+    """inf hop distance -> h = 0; a row whose every h*a underflows -> 0/0 = NaN like the reference"""
+    rng = np.random.default_rng(2)
+    X = rng.normal(size=(300, 6))
+    W = rng.normal(size=(4, 6))
+    W[3] += 100.0  # dead
+    hop = np.array([[0, 1, np.inf, np.inf], [1, 0, np.inf, np.inf],
+                    [np.inf, np.inf, 0, 1], [np.inf, np.inf, 1, 0]], dtype=np.float64)
+    hip.load(X)
+    res = hip.epoch(W, hop, 0.8, 0.1, "aligned", True)
+    oo = o.epoch(X, W, hop, 0.8, np.float64(10.0), "aligned", "chain")
+    np.testing.assert_allclose(res.new_weights, oo.new_weights, rtol=1e-11, equal_nan=True)
+
+
+def test_determinism_bitwise(hip):
+    X, W = _rand(20000, 64, 100, np.float32, 42)
+    hip.load(X)
+    hop = gi.lattice_hops(10, 10)
+    r1 = hip.epoch(W, hop, 2.0, 0.01, "compact", True)
+    r2 = hip.epoch(W, hop, 2.0, 0.01, "compact", True)
+    assert np.array_equal(r1.new_weights, r2.new_weights)  # no float atomics anywhere
+    assert np.array_equal(r1.errors, r2.errors) and r1.change_total == r2.change_total
+
+
+def test_ctx_api_numpy_only(o):
+    """The context-level ABI a NumPy caller (the reference) would bind: host pointers only."""
+    from dbgsom_amd import _native as nat
+
+    lib = nat.load()
+    rng = np.random.default_rng(1)
+    N, d, rows, cols = 3000, 24, 4, 5
+    M = rows * cols
+    X = rng.normal(size=(N, d)).astype(np.float32)
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    hop = gi.lattice_hops(rows, cols)
+    ctx = ctypes.c_void_p()
+    nat.call("dbgsom_ctx_create", 0, ctypes.byref(ctx))
+    try:
+        nat.call("dbgsom_ctx_load", ctx, X.ctypes.data, nat.F32, N, d)
+        nat.call("dbgsom_ctx_set_topology", ctx, hop.ctypes.data, M)
+        idx = np.empty((N, 2), np.int64)
+        dist = np.empty((N, 2), np.float64)
+        nat.call("dbgsom_ctx_bmu", ctx, W.ctypes.data, M, 2, 0, idx.ctypes.data, dist.ctypes.data)
+        rd, ri = o.bmu_chain(X, W, 2)
+        assert np.array_equal(idx, ri) and np.array_equal(dist, rd)
+        Wn = np.empty((M, d)); chg = np.empty(1); E = np.empty(M); a = np.empty(M)
+        i1 = np.empty(N, np.int64); d1 = np.empty(N)
+        gamma = float(np.var(X, axis=0).sum() ** -1)
+        nat.call("dbgsom_ctx_epoch", ctx, W.ctypes.data, M, 0, gamma, 0.9, nat.CENTRES_COMPACT,
+                 Wn.ctypes.data, chg.ctypes.data, E.ctypes.data, a.ctypes.data, i1.ctypes.data,
+                 d1.ctypes.data)
+        oo = o.epoch(X, W, hop, 0.9, np.var(X, axis=0).sum(), "compact", "chain")
+        assert np.array_equal(i1, oo.winners) and np.array_equal(d1, oo.distances)
+        np.testing.assert_allclose(Wn, oo.new_weights, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(E, oo.errors, rtol=1e-12)
+        assert np.array_equal(a, oo.activations)
+        Xq = rng.normal(size=(50, d))
+        iq = np.empty((50, 1), np.int64); dq = np.empty((50, 1))
+        nat.call("dbgsom_ctx_bmu_query", ctx, Xq.ctypes.data, nat.F64, 50, d, W.ctypes.data, M, 1,
+                 0, iq.ctypes.data, dq.ctypes.data)
+        rd, ri = o.bmu_chain(Xq, W, 1)
+        assert np.array_equal(iq.ravel(), ri) and np.array_equal(dq.ravel(), rd)
+        # error behaviour: status codes + message, nothing thrown across the ABI
+        rc = lib.dbgsom_ctx_bmu(ctx, W.ctypes.data, M, 3, 0, idx.ctypes.data, dist.ctypes.data)
+        assert rc == -1 and b"bad arguments" in lib.dbgsom_last_error()
+        rc = lib.dbgsom_ctx_epoch(ctx, W.ctypes.data, M - 1, 0, gamma, 0.9, 0, Wn.ctypes.data,
+                                  chg.ctypes.data, E.ctypes.data, a.ctypes.data, None, None)
+        assert rc == -4
+    finally:
+        nat.call("dbgsom_ctx_destroy", ctx)
+
+
+def test_full_size_properties(hip, o):
+    """BASELINE config C4 shape (N=1e6, d=784, M=1024): size-independent properties + an oracle
+    spot check on a sample subset."""
+    import torch
+
+    N, d, rows, cols = 1_000_000, 784, 32, 32
+    M = rows * cols
+    gen = torch.Generator(device="cuda").manual_seed(1004)
+    centers = torch.randn(32, d, device="cuda", generator=gen) * 4
+    lab = torch.randint(0, 32, (N,), device="cuda", generator=gen)
+    X = (centers[lab] + torch.randn(N, d, device="cuda", generator=gen)).float()
+    del lab
+    hip.load_device(X)
+    sel = torch.randperm(N, device="cuda", generator=gen)[:M]
+    W = X[sel].double().cpu().numpy()
+    hop = gi.lattice_hops(rows, cols)
+    gamma = float(1.0 / X.double().var(dim=0, unbiased=False).sum().item())
+    res = hip.epoch(W, hop, 0.2 * np.sqrt(M), gamma, "compact", True)
+    win, dist = res.winners, res.distances
+    # (1) oracle spot check: 3000 random samples, bit-exact
+    pick = np.random.default_rng(0).choice(N, 3000, replace=False)
+    Xs = X[torch.from_numpy(pick).cuda()].cpu().numpy()
+    rd, ri = o.bmu_chain(Xs, W, 1)
+    assert np.array_equal(win[pick], ri) and np.array_equal(dist[pick], rd)
+    # (2) the samples that ARE prototypes find themselves (or an identical earlier row) at r ~ 0
+    assert (dist[sel.cpu().numpy()] < 1e-4).all()
+    # (3) conservation: hits sum to N, E sums to sum(dist), S sums to sum(kw * x)
+    assert res.activations.sum() == N
+    np.testing.assert_allclose(res.errors.sum(), dist.sum(), rtol=1e-10)
+    kw = 1 - np.sqrt(1 - np.exp(-gamma * dist ** 2))
+    sums, _, _ = hip._local_sums(W, gamma, False)
+    S = sums[: M * d].view(M, d)
+    col_ref = (torch.from_numpy(kw).cuda()[None, :] @ X.double()).view(-1)
+    np.testing.assert_allclose(S.sum(dim=0).cpu().numpy(), col_ref.cpu().numpy(), rtol=1e-9)
+    # (4) permutation equivariance of the BMU step
+    perm = torch.randperm(N, device="cuda", generator=gen)
+    hip.load_device(X[perm].contiguous())
+    d2, i2 = hip.bmu(W, 1)
+    p = perm.cpu().numpy()
+    assert np.array_equal(i2, win[p]) and np.array_equal(d2, dist[p])
+    hip.release()
