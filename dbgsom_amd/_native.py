@@ -45,6 +45,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_hip_rt = None
 
 
 class DbgsomNativeError(RuntimeError):
@@ -63,9 +64,35 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def _load_hip_runtime():
+    """Make ONE HIP runtime visible process-wide before the library (linked with -no-hip-rt)
+    is loaded: the copy PyTorch bundles when torch is installed (so torch's streams and
+    allocations are valid in our launches), else the system ROCm one."""
+    candidates = []
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            candidates.append(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+    except (ImportError, ValueError):  # pragma: no cover
+        pass
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    candidates += [os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so"]
+    errors = []
+    for path in candidates:
+        if os.path.isabs(path) and not os.path.exists(path):
+            continue
+        try:
+            return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError as e:  # try the next candidate
+            errors.append(f"{path}: {e}")
+    raise RuntimeError("no HIP runtime (libamdhip64.so) could be loaded: " + "; ".join(errors))
+
+
 def load():
     """Load the HIP library; raises (never falls back) when it is not built."""
-    global _lib
+    global _lib, _hip_rt
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
@@ -73,6 +100,7 @@ def load():
             f"{LIB_PATH} is missing: the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C dbgsom_amd/csrc`). "
             "dbgsom_amd has no CPU fallback.")
+    _hip_rt = _load_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -124,7 +124,9 @@ class HipBackend(HotPathBackend):
 
         if not torch.cuda.is_available() or _native.device_count() < 1:
             raise RuntimeError(
-                "dbgsom_amd.HipBackend needs a visible AMD GPU (MI355X / gfx950); none found. "
+                "dbgsom_amd.HipBackend needs a visible AMD GPU (MI355X / gfx950); found "
+                f"torch.cuda.is_available()={torch.cuda.is_available()}, "
+                f"hipGetDeviceCount()={_native.device_count()}. "
                 "There is no CPU fallback in the product path.")
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()

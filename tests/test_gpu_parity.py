@@ -77,7 +77,7 @@ def test_bmu_query_path_and_f32_pair_rounding(hip, o):
     assert np.array_equal(iq, rqi) and np.array_equal(dq, rq)
 
 
-def test_ties_lowest_index(hip):
+def test_ties_lowest_index(hip, o):
     X = np.array([[1.0, 2.0, 3.0], [0.0, 0.0, 0.0], [2.0, 2.0, 2.0]], dtype=np.float64)
     W = np.array([[5.0, 5.0, 5.0], [1.0, 2.0, 3.0], [1.0, 2.0, 3.0], [0.0, 0.0, 0.0]])
     hip.load(X)
@@ -92,7 +92,9 @@ def test_ties_lowest_index(hip):
     hip.load(X2)
     d2, i2 = hip.bmu(W2, 2)
     assert (i2[:, 0] < 6).all()                 # lowest copy wins
-    assert (i2[:, 1] == i2[:, 0] + 6).all()     # second = next copy of the same row
+    rd, ri = o.bmu_chain(X2, W2, 2)             # exact integer arithmetic: every tie is a true tie
+    assert np.array_equal(i2, ri) and np.array_equal(d2, rd)
+    assert (d2[:, 0] == d2[:, 1]).all() and (i2[:, 1] > i2[:, 0]).all()
 
 
 @pytest.mark.parametrize("name", gi.FIT_CASES)
