@@ -139,6 +139,9 @@ class HipBackend(HotPathBackend):
         self._hop_key = None
         self._hop_dev = None
         self._ws = {}
+        # bench hook: a list here collects (name, start, end) HIP events recorded on the stream
+        # the kernels are launched on
+        self.kernel_events = None
 
     # -- helpers --------------------------------------------------------------------------------
     def _stream(self):
@@ -147,6 +150,18 @@ class HipBackend(HotPathBackend):
     @staticmethod
     def _p(t):
         return ctypes.c_void_p(t.data_ptr())
+
+    def _timed_call(self, key, fn_name, *args):
+        if self.kernel_events is None:
+            _native.call(fn_name, *args)
+            return
+        ev = self._torch.cuda.Event
+        a, b = ev(enable_timing=True), ev(enable_timing=True)
+        stream = self._torch.cuda.current_stream(self.device)
+        a.record(stream)
+        _native.call(fn_name, *args)
+        b.record(stream)
+        self.kernel_events.append((key, a, b))
 
     def _buf(self, key, nbytes):
         """Reusable byte workspace (torch caching allocator blocks are >= 512-B aligned)."""
@@ -210,7 +225,7 @@ class HipBackend(HotPathBackend):
         M = Wd.shape[0]
         idx = torch.empty((N, k), dtype=torch.int64, device=self.device)
         dist = torch.empty((N, k), dtype=torch.float64, device=self.device)
-        _native.call("dbgsom_bmu", self._p(Xd), _x_dtype_code(xdtype), N, d, d, self._p(xxd),
+        self._timed_call("bmu", "dbgsom_bmu", self._p(Xd), _x_dtype_code(xdtype), N, d, d, self._p(xxd),
                      self._p(Wd), M, self._p(wwd), k, round_f32, self._p(idx), self._p(dist),
                      self._stream())
         return dist, idx
@@ -258,7 +273,7 @@ class HipBackend(HotPathBackend):
         need = self._lib.dbgsom_accumulate_workspace_bytes(N, d, M)
         ws = self._buf("acc", need)
         status = self._buf("status", 256)
-        _native.call("dbgsom_accumulate", self._p(self._X), _x_dtype_code(self._x_np_dtype), N, d,
+        self._timed_call("accumulate", "dbgsom_accumulate", self._p(self._X), _x_dtype_code(self._x_np_dtype), N, d,
                      d, self._p(idx_dev), self._p(kw_dev), self._p(dist_dev), M, self._p(sums),
                      self._p(status), self._p(ws), ws.numel(), self._stream())
         return sums
@@ -310,7 +325,7 @@ class HipBackend(HotPathBackend):
         chg = torch.empty(1, dtype=torch.float64, device=self.device)
         need = self._lib.dbgsom_smooth_workspace_bytes(M, d)
         ws = self._buf("smooth", need)
-        _native.call("dbgsom_smooth", self._p(sums), M, d, self._p(hop_d), float(sigma),
+        self._timed_call("smooth", "dbgsom_smooth", self._p(sums), M, d, self._p(hop_d), float(sigma),
                      _native.LAYOUTS[layout], self._p(Wd), self._p(Wn), self._p(chg), self._p(ws),
                      ws.numel(), self._stream())
         tail = sums[M * d:].cpu().numpy()
