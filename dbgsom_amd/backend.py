@@ -104,6 +104,11 @@ class HotPathBackend:
     def release(self):
         pass
 
+    def __deepcopy__(self, memo):
+        # sklearn.clone deep-copies constructor parameters; device handles are not copyable,
+        # a fresh backend with the same configuration is what a cloned estimator needs
+        return self.__class__(*getattr(self, "_init_args", ()))
+
 
 def _x_dtype_code(dt) -> int:
     if dt == np.float32:
@@ -120,6 +125,7 @@ class HipBackend(HotPathBackend):
 
     def __init__(self, device: Optional[int] = None):
         self._lib = _native.load()  # raises when the extension is not built
+        self._init_args = (device,)
         import torch
 
         if not torch.cuda.is_available() or _native.device_count() < 1:

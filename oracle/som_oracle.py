@@ -314,6 +314,7 @@ class OracleBackend(_backend_base()):
 
     def __init__(self, bmu: str = "chain"):
         self._fn = {"chain": bmu_chain, "blas": bmu_blas, "sklearn": bmu_sklearn}[bmu]
+        self._init_args = (bmu,)
         self._X = None
 
     def load(self, X):
