@@ -65,6 +65,12 @@ def cpu_baseline(workload, Xs, W, hop, sigma, gamma, n_full):
     except ImportError:
         bmu, engine = o.bmu_blas, "NumPy dgemm expanded-L2"
     M = W.shape[0]
+    # size the sample for ~15 s of CPU work: probe the BMU rate on 10k rows first
+    tp = time.perf_counter()
+    bmu(Xs[:10_000], W, 1)
+    rate = 10_000 / (time.perf_counter() - tp)
+    ns = int(min(Xs.shape[0], max(20_000, rate * 15.0)))
+    Xs = Xs[:ns]
     t0 = time.perf_counter()
     dist, win = bmu(Xs, W, 1)
     t1 = time.perf_counter()
@@ -75,7 +81,6 @@ def cpu_baseline(workload, Xs, W, hop, sigma, gamma, n_full):
     Wn = o.smooth_matmul(o.gaussian_neighborhood(hop, sigma), a, C)
     o.change_total(W, Wn)
     t3 = time.perf_counter()
-    ns = Xs.shape[0]
     t_epoch = (t2 - t0) * (n_full / ns) + (t3 - t2)
     try:
         from threadpoolctl import threadpool_info
@@ -102,8 +107,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--samples-per-gpu", type=int, default=None, help="override N per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=40_000,
-                    help="rows timed by the CPU baseline (0 disables it)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000,
+                    help="upper bound of rows timed by the CPU baseline (0 disables it); the "
+                         "actual sample is sized for ~15 s of CPU work")
     args = ap.parse_args()
 
     import torch
@@ -154,13 +160,15 @@ def main():
         torch.cuda.synchronize()
 
     hip.kernel_events = None
+    # prototypes stay in HBM between steps (a training phase without growth); the per-neuron
+    # errors, hit counts and the convergence norm come back to the host every step
     for _ in range(args.warmup):
-        W = hip.epoch(W, hop, sigma, gamma, "compact", False).new_weights
+        W = hip.epoch(W, hop, sigma, gamma, "compact", False, keep_on_device=True).new_weights_dev
     hip.kernel_events = []  # HIP events around the BMU and accumulate launches (their stream)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        W = hip.epoch(W, hop, sigma, gamma, "compact", False).new_weights
+        W = hip.epoch(W, hop, sigma, gamma, "compact", False, keep_on_device=True).new_weights_dev
     sync()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)

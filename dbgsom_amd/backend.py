@@ -35,6 +35,7 @@ class EpochResult:
     activations: np.ndarray      # (M,) hit counts
     winners: Optional[np.ndarray] = None    # (N_local,) int64
     distances: Optional[np.ndarray] = None  # (N_local,) float64
+    new_weights_dev: object = None          # device-resident copy (HipBackend, keep_on_device)
 
 
 def shard_bounds(n: int, rank: int, world: int):
@@ -284,17 +285,25 @@ class HipBackend(HotPathBackend):
                      self._p(status), self._p(ws), ws.numel(), self._stream())
         return sums
 
+    def _as_dev_weights(self, W):
+        """(device float64 tensor, round_f32 flag) from a NumPy array or a device tensor that a
+        previous epoch left in HBM."""
+        if self._torch.is_tensor(W):
+            if W.dtype != self._torch.float64 or W.device != self.device or not W.is_contiguous():
+                raise ValueError("device weights must be a contiguous float64 tensor on the backend's GPU")
+            return W, 0
+        W = np.asarray(W)
+        return self._dev_f64(W), self._round_f32(W, self._x_np_dtype)
+
     def _local_sums(self, W, gamma, want_assignments):
         self._require_loaded()
-        W = np.asarray(W)
-        Wd = self._dev_f64(W)
+        Wd, rf = self._as_dev_weights(W)
         self._W_dev = Wd
-        wwd = self._norms(Wd, _native.F64, W.shape[0], W.shape[1])
-        dist, idx = self._bmu_dev(self._X, self._xx, self._x_np_dtype, Wd, wwd, 1,
-                                  self._round_f32(W, self._x_np_dtype))
+        wwd = self._norms(Wd, _native.F64, Wd.shape[0], Wd.shape[1])
+        dist, idx = self._bmu_dev(self._X, self._xx, self._x_np_dtype, Wd, wwd, 1, rf)
         dist, idx = dist.view(-1), idx.view(-1)
         kw = self._exp_similarity_dev(dist, gamma)
-        sums = self._accumulate_dev(idx, kw, dist, W.shape[0])
+        sums = self._accumulate_dev(idx, kw, dist, Wd.shape[0])
         if want_assignments:
             return sums, idx.cpu().numpy(), dist.cpu().numpy()
         return sums, None, None
@@ -317,13 +326,28 @@ class HipBackend(HotPathBackend):
             self._hop_key = hop
         return self._hop_dev
 
-    def _smooth(self, sums, W, hop, sigma, layout):
+    def epoch(self, W, hop, sigma, gamma, layout="compact", want_assignments=False,
+              keep_on_device=False):
+        """One hot-path epoch.  `W` may be a NumPy array or the `new_weights_dev` tensor of the
+        previous epoch; with `keep_on_device` the new prototypes stay in HBM (no PCIe round trip
+        between epochs of a phase without growth) and only the O(M) statistics come back."""
+        sums, win, dist = self._local_sums(W, gamma, want_assignments)
+        sums = self._all_reduce(sums)
+        Wn, chg, E, a = self._smooth(sums, W, hop, sigma, layout, keep_on_device)
+        if keep_on_device:
+            return EpochResult(None, chg, E, a, win, dist, Wn)
+        return EpochResult(Wn, chg, E, a, win, dist)
+
+    def _smooth(self, sums, W, hop, sigma, layout, keep_on_device=False):
         torch = self._torch
-        W = np.asarray(W)
-        M, d = W.shape
+        if torch.is_tensor(W):
+            M, d = W.shape
+        else:
+            W = np.asarray(W)
+            M, d = W.shape
         Wd = getattr(self, "_W_dev", None)
         if Wd is None or tuple(Wd.shape) != (M, d):
-            Wd = self._dev_f64(W)
+            Wd, _ = self._as_dev_weights(W)
         hop_d = self._hop(hop)
         if tuple(hop_d.shape) != (M, M):
             raise ValueError("hop matrix must be (M, M)")
@@ -338,7 +362,9 @@ class HipBackend(HotPathBackend):
         status = int(self._ws["status"][:4].view(torch.int32).item()) if "status" in self._ws else 0
         if status:
             raise _native.DbgsomNativeError("dbgsom_accumulate", -5, "winner index out of range")
-        return Wn.cpu().numpy(), float(chg.item()), tail[2 * M:3 * M].copy(), tail[M:2 * M].copy()
+        self._W_dev = None
+        Wout = Wn if keep_on_device else Wn.cpu().numpy()
+        return Wout, float(chg.item()), tail[2 * M:3 * M].copy(), tail[M:2 * M].copy()
 
     def release(self):
         self._X = self._xx = self._hop_dev = None

@@ -195,15 +195,28 @@ class BaseSom(BaseEstimator):
 
             epochs = tqdm(iterable=epochs, unit=" epochs")
         need_assign = self.growth_criterion == "entropy"
+        # In the fine phase the lattice no longer changes: the prototypes then stay in HBM from
+        # one epoch to the next and come back to the host once, at the end.
+        can_chain = hasattr(engine, "load_device")
+        w_dev = w_dev_prev = None
         for epoch in epochs:
             self._current_epoch = epoch
             if epoch > self.coarse_training_frac * self.n_iter:
                 self._training_phase = "fine"
-            self._sync_views(refresh_weights=True)  # hop matrix recomputed only after growth
+            chain = can_chain and self._training_phase == "fine"
+            if w_dev is None:
+                self._sync_views(refresh_weights=True)  # hop matrix recomputed only after growth
+                w_in = self.weights_
+            else:
+                w_in = w_dev
 
-            res = engine.epoch(self.weights_, self._distance_matrix, self._calculate_current_sigma(),
-                               self._gamma(), self.centres_layout, want_assignments=need_assign)
-            lat.set_weights(res.new_weights)  # like the reference: the graph moves on, the
+            res = engine.epoch(w_in, self._distance_matrix, self._calculate_current_sigma(),
+                               self._gamma(), self.centres_layout, want_assignments=need_assign,
+                               **({"keep_on_device": True} if chain else {}))
+            if chain:
+                w_dev_prev, w_dev = w_in, res.new_weights_dev
+            else:
+                lat.set_weights(res.new_weights)  # like the reference: the graph moves on, the
             if res.change_total < self.convergence_treshold:  # weights_ snapshot stays (Q3)
                 self.converged_ = True
             if need_assign:
@@ -218,6 +231,10 @@ class BaseSom(BaseEstimator):
                     and epoch % self.convergence_iter == self.convergence_iter - 1):
                 lat.distribute_errors(self.growing_threshold_)
                 lat.grow(self.growing_threshold_, epoch)
+        if w_dev is not None:
+            if not isinstance(w_dev_prev, np.ndarray):
+                self.weights_ = w_dev_prev.cpu().numpy()  # the snapshot the last epoch consumed
+            lat.set_weights(w_dev.cpu().numpy())
         lat.write_attributes()
 
     def _gamma(self) -> float:

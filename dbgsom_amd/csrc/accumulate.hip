@@ -86,7 +86,15 @@ __global__ void colscan_kernel(uint32_t *__restrict__ blk, int64_t nb, int M,
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
     uint32_t run = 0;
-    for (int64_t b = 0; b < nb; ++b) {
+    int64_t b = 0;
+    for (; b + 8 <= nb; b += 8) {  // 8 independent loads in flight, then the serial prefix
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = blk[(size_t)(b + u) * M + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { blk[(size_t)(b + u) * M + j] = run; run += c[u]; }
+    }
+    for (; b < nb; ++b) {
         const uint32_t c = blk[(size_t)b * M + j];
         blk[(size_t)b * M + j] = run;
         run += c;
@@ -265,7 +273,15 @@ __global__ __launch_bounds__(AT) void finalize_kernel(const double *__restrict__
     double *Kp = sums + (size_t)M * d, *ap = Kp + M, *Ep = ap + M;
     for (int col = threadIdx.x; col < d + 2; col += AT) {
         double s = 0.0;
-        for (uint32_t c = c0; c < c1; ++c) s += slab[(size_t)c * (d + 2) + col];
+        uint32_t c = c0;
+        for (; c + 8 <= c1; c += 8) {  // loads batched, additions still in chunk order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(c + u) * (d + 2) + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c < c1; ++c) s += slab[(size_t)c * (d + 2) + col];
         if (col < d) S[col] = s;
         else if (col == d) Kp[j] = s;
         else Ep[j] = s;

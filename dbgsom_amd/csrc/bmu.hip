@@ -108,8 +108,10 @@ __global__ __launch_bounds__(NT, 2) void bmu_kernel(
     const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
     const double *__restrict__ W, int M, const double *__restrict__ ww, int round_f32, int xvec,
     int wvec, int64_t *__restrict__ idx_out, double *__restrict__ dist_out) {
-    __shared__ __attribute__((aligned(16))) double xs[BI * LS];
-    __shared__ __attribute__((aligned(16))) double wsm[BJ * LS];
+    // double-buffered operand tiles: tile t+1 is written while tile t feeds the MFMAs, one
+    // barrier per tile
+    __shared__ __attribute__((aligned(16))) double xs[2][BI * LS];
+    __shared__ __attribute__((aligned(16))) double wsm[2][BJ * LS];
     __shared__ double yy_s[2][BJ];
 
     const int tid = threadIdx.x;
@@ -130,74 +132,91 @@ __global__ __launch_bounds__(NT, 2) void bmu_kernel(
 
     const int lrow = tid >> 1, lk = (tid & 1) * 8;  // staging: 2 threads per tile row, 8 values each
     const int nkt = (d + KT - 1) / KT;
+    const int nchunk = (M + BJ - 1) / BJ;
+    const int ntile = nkt * nchunk;  // flat (chunk, k-tile) sequence: the pipeline never drains
     XT xr[8];
     double wr[8];
 
-    int parity = 0;
-    for (int jc = 0; jc < M; jc += BJ, parity ^= 1) {
-        d4_t acc[4][4];
+    auto stage_store = [&](int buf) {
+        double *xd = &xs[buf][lrow * LS + lk];
+        double *wd = &wsm[buf][lrow * LS + lk];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int it = 0; it < 4; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
-
-        load8<XT>(X, i0 + lrow, N, ldx, lk, d, xvec, xr);
-        load8<double>(W, (int64_t)jc + lrow, M, d, lk, d, wvec, wr);
-        if (tid < BJ) yy_s[parity][tid] = (jc + tid < M) ? ww[jc + tid] : 0.0;
-
-        for (int kt = 0; kt < nkt; ++kt) {
-            __syncthreads();  // every wavefront is done reading the previous tile
-            {
-                double *xd = &xs[lrow * LS + lk];
-                double *wd = &wsm[lrow * LS + lk];
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    *reinterpret_cast<double2 *>(xd + e) =
-                        double2{(double)xr[e], (double)xr[e + 1]};
-                    *reinterpret_cast<double2 *>(wd + e) = double2{wr[e], wr[e + 1]};
-                }
-            }
-            __syncthreads();
-            if (kt + 1 < nkt) {  // next tile's loads fly under this tile's MFMAs
-                const int kn = (kt + 1) * KT + lk;
-                load8<XT>(X, i0 + lrow, N, ldx, kn, d, xvec, xr);
-                load8<double>(W, (int64_t)jc + lrow, M, d, kn, d, wvec, wr);
-            }
-#pragma unroll
-            for (int ks = 0; ks < KT / 4; ++ks) {
-                double a[4], b[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    a[t] = wsm[(wj * 64 + t * 16 + lr) * LS + ks * 4 + lq];
-                    b[t] = xs[(wi * 64 + t * 16 + lr) * LS + ks * 4 + lq];
-                }
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                    for (int it = 0; it < 4; ++it)
-                        acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt], b[it],
-                                                                           acc[jt][it], 0, 0, 0);
-            }
+        for (int e = 0; e < 8; e += 2) {
+            *reinterpret_cast<double2 *>(xd + e) = double2{(double)xr[e], (double)xr[e + 1]};
+            *reinterpret_cast<double2 *>(wd + e) = double2{wr[e], wr[e + 1]};
         }
+    };
 
-        // chunk epilogue: expanded L2 + running arg-k-min (prototype index ascends per lane)
+    d4_t acc[4][4];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
+    for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int jl = wj * 64 + jt * 16 + 4 * r + lq;
-                const int j = jc + jl;
-                const double y = yy_s[parity][jl];
-                if (j < M) {
+        for (int it = 0; it < 4; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    load8<XT>(X, i0 + lrow, N, ldx, lk, d, xvec, xr);
+    load8<double>(W, (int64_t)lrow, M, d, lk, d, wvec, wr);
+    if (tid < BJ) yy_s[0][tid] = (tid < M) ? ww[tid] : 0.0;
+    stage_store(0);
+    __syncthreads();
+
+    int kt = 0, jc = 0, parity = 0;
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        // next tile in the flat sequence
+        int kt_n = kt + 1, jc_n = jc;
+        if (kt_n == nkt) { kt_n = 0; jc_n = jc + BJ; }
+        const bool more = (t + 1 < ntile);
+        if (more) {  // its global loads fly under this tile's MFMAs
+            const int kn = kt_n * KT + lk;
+            load8<XT>(X, i0 + lrow, N, ldx, kn, d, xvec, xr);
+            load8<double>(W, (int64_t)jc_n + lrow, M, d, kn, d, wvec, wr);
+            if (kt_n == 0 && tid < BJ)
+                yy_s[parity ^ 1][tid] = (jc_n + tid < M) ? ww[jc_n + tid] : 0.0;
+        }
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        double rv = (xi[it] + (-2.0 * acc[jt][it][r])) + y;
-                        if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;  // max(r, 0), NaN kept
-                        best[it].push(rv, j);
+        for (int ks = 0; ks < KT / 4; ++ks) {
+            if (ks == KT / 8 && more) stage_store(cur ^ 1);  // half-way: loads have landed
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = wsm[cur][(wj * 64 + u * 16 + lr) * LS + ks * 4 + lq];
+                b[u] = xs[cur][(wi * 64 + u * 16 + lr) * LS + ks * 4 + lq];
+            }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt], b[it], acc[jt][it],
+                                                                       0, 0, 0);
+        }
+        if (kt == nkt - 1) {
+            // chunk epilogue: expanded L2 + running arg-k-min (prototype index ascends per lane)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jl = wj * 64 + jt * 16 + 4 * r + lq;
+                    const int j = jc + jl;
+                    const double y = yy_s[parity][jl];
+                    if (j < M) {
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            double rv = (xi[it] + (-2.0 * acc[jt][it][r])) + y;
+                            if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;  // max(r, 0), NaN kept
+                            best[it].push(rv, j);
+                        }
                     }
                 }
             }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
+            parity ^= 1;
         }
+        __syncthreads();  // tile t+1 is complete in LDS; tile t's buffer may be overwritten next
+        kt = kt_n;
+        jc = jc_n;
     }
 
     // lanes l, l^16, l^32, l^48 hold the same sample against different prototypes
@@ -217,9 +236,8 @@ __global__ __launch_bounds__(NT, 2) void bmu_kernel(
     }
 
     // the two wavefronts with the same `wi` hold the two prototype halves of the same samples
-    __syncthreads();
-    double *mv = xs;                             // [2][BI][K]
-    int *mj = reinterpret_cast<int *>(wsm);      // [2][BI][K]
+    double *mv = &xs[0][0];                            // [2][BI][K]
+    int *mj = reinterpret_cast<int *>(&wsm[0][0]);     // [2][BI][K]
     if (lq == 0) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -261,36 +279,38 @@ __global__ __launch_bounds__(NT, 2) void bmu_kernel(
 // squared row norms, sequential fma chain per row (same order as the oracle); rows are staged
 // through LDS so the global reads stay coalesced while each thread walks its own row.
 // ---------------------------------------------------------------------------------------------
-constexpr int NR = 128;  // rows per workgroup (= threads)
-constexpr int NK = 32;   // features per staged tile
+// Two shapes of the same kernel: 128 rows x 32 features per staged tile for the sample matrix
+// (one thread per row walks the chain), 16 rows x 256 features for the small prototype matrix
+// (more workgroups, fewer dependent load rounds: it is latency-bound at M ~ 1000).
+constexpr int NORM_THREADS = 128;
 
-template <typename T>
-__global__ __launch_bounds__(NR) void row_sqnorms_kernel(const T *__restrict__ A, int64_t rows,
-                                                         int d, int64_t ld,
-                                                         double *__restrict__ out) {
+template <typename T, int NR, int NK>
+__global__ __launch_bounds__(NORM_THREADS) void row_sqnorms_kernel(const T *__restrict__ A,
+                                                                   int64_t rows, int d, int64_t ld,
+                                                                   double *__restrict__ out) {
     __shared__ double tile[NR][NK + 1];
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * NR;
     double acc = 0.0;
     for (int k0 = 0; k0 < d; k0 += NK) {
         __syncthreads();
-        // 128 x 32 elements, 32 consecutive features per row-group of 32 threads
-        const int c = tid & 31, rg = tid >> 5;
-#pragma unroll 4
-        for (int p = 0; p < NR / 4; ++p) {
-            const int r = p * 4 + rg;
+#pragma unroll 8
+        for (int e = tid; e < NR * NK; e += NORM_THREADS) {
+            const int r = e / NK, c = e % NK;  // consecutive threads -> consecutive features
             const int64_t row = r0 + r;
             const int k = k0 + c;
             tile[r][c] = (row < rows && k < d) ? (double)A[row * ld + k] : 0.0;
         }
         __syncthreads();
-        const int kmax = min(NK, d - k0);
-        for (int kk = 0; kk < kmax; ++kk) {
-            const double v = tile[tid][kk];
-            acc = fma(v, v, acc);
+        if (tid < NR) {
+            const int kmax = min(NK, d - k0);
+            for (int kk = 0; kk < kmax; ++kk) {
+                const double v = tile[tid][kk];
+                acc = fma(v, v, acc);
+            }
         }
     }
-    if (r0 + tid < rows) out[r0 + tid] = acc;
+    if (tid < NR && r0 + tid < rows) out[r0 + tid] = acc;
 }
 
 __global__ void exp_similarity_kernel(const double *__restrict__ dist, int64_t N, double gamma,
@@ -309,14 +329,18 @@ int launch_row_sqnorms(const void *A, int dtype, int64_t rows, int64_t d, int64_
     DBGSOM_REQUIRE(rows >= 0 && d >= 1 && ld >= d && d <= 0x7fffffff, "bad shape");
     if (rows == 0) return DBGSOM_OK;
     DBGSOM_REQUIRE(A && out, "null pointer");
-    const int64_t nb = (rows + NR - 1) / NR;
+    const bool small = rows <= 16384;
+    const int nr = small ? 16 : 128;
+    const int64_t nb = (rows + nr - 1) / nr;
     DBGSOM_REQUIRE(nb <= 0x7fffffff, "too many rows");
-    if (dtype == DBGSOM_F32)
-        hipLaunchKernelGGL(row_sqnorms_kernel<float>, dim3((unsigned)nb), dim3(NR), 0, s,
-                           (const float *)A, rows, (int)d, ld, out);
-    else
-        hipLaunchKernelGGL(row_sqnorms_kernel<double>, dim3((unsigned)nb), dim3(NR), 0, s,
-                           (const double *)A, rows, (int)d, ld, out);
+    dim3 grid((unsigned)nb), block(NORM_THREADS);
+    if (dtype == DBGSOM_F32) {
+        if (small) hipLaunchKernelGGL((row_sqnorms_kernel<float, 16, 256>), grid, block, 0, s, (const float *)A, rows, (int)d, ld, out);
+        else hipLaunchKernelGGL((row_sqnorms_kernel<float, 128, 32>), grid, block, 0, s, (const float *)A, rows, (int)d, ld, out);
+    } else {
+        if (small) hipLaunchKernelGGL((row_sqnorms_kernel<double, 16, 256>), grid, block, 0, s, (const double *)A, rows, (int)d, ld, out);
+        else hipLaunchKernelGGL((row_sqnorms_kernel<double, 128, 32>), grid, block, 0, s, (const double *)A, rows, (int)d, ld, out);
+    }
     return launch_status("row_sqnorms_kernel");
 }
 
