@@ -35,6 +35,11 @@ SIGNATURES = {
                                 _sz, _vp]),
     "dbgsom_smooth_workspace_bytes": (_sz, [_i64, _i64]),
     "dbgsom_smooth": (_ci, [_vp, _i64, _i64, _vp, _dbl, _ci, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dbgsom_sum_workspace_bytes": (_sz, []),
+    "dbgsom_sum_f64": (_ci, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "dbgsom_topographic_count": (_ci, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "dbgsom_density_terms": (_ci, [_vp, _i64, _dbl, _vp, _vp]),
+    "dbgsom_class_histogram": (_ci, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dbgsom_ctx_create": (_ci, [_ci, ctypes.POINTER(_vp)]),
     "dbgsom_ctx_destroy": (_ci, [_vp]),
     "dbgsom_ctx_load": (_ci, [_vp, _vp, _ci, _i64, _i64]),

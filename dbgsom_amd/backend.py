@@ -36,6 +36,7 @@ class EpochResult:
     winners: Optional[np.ndarray] = None    # (N_local,) int64
     distances: Optional[np.ndarray] = None  # (N_local,) float64
     new_weights_dev: object = None          # device-resident copy (HipBackend, keep_on_device)
+    class_hist: Optional[np.ndarray] = None  # (M, n_classes) int64 when labels were attached
 
 
 def shard_bounds(n: int, rank: int, world: int):
@@ -91,16 +92,62 @@ class HotPathBackend:
             td.all_reduce(sums, op=td.ReduceOp.SUM)  # one collective per epoch
         return sums
 
-    def epoch(self, W, hop, sigma, gamma, layout="compact", want_assignments=False):
-        sums, win, dist = self._local_sums(W, gamma, want_assignments)
+    def epoch(self, W, hop, sigma, gamma, layout="compact", want_assignments=False,
+              n_classes=0):
+        sums, win, dist = self._local_sums(W, gamma, want_assignments or n_classes > 0)
         sums = self._all_reduce(sums)
         Wn, chg, E, a = self._smooth(sums, W, hop, sigma, layout)
-        return EpochResult(Wn, chg, E, a, win, dist)
+        res = EpochResult(Wn, chg, E, a, win if want_assignments else None,
+                          dist if want_assignments else None)
+        if n_classes > 0:
+            res.class_hist = self.class_histogram(win, n_classes, np.asarray(W).shape[0])
+        return res
 
     def update(self, W, hop, sigma, sample_weights, winners, distances, layout="compact"):
         sums = self._sums_from(W, sample_weights, winners, distances)
         sums = self._all_reduce(sums)
         return self._smooth(sums, W, hop, sigma, layout)
+
+    # -- post-fit consumers of the BMU step; host defaults ----------
+    def _reduce_host(self, arr):
+        """Sum a small host array over the ranks (identity for one process)."""
+        rank, world = dist_info()
+        if world == 1:
+            return arr
+        import torch
+
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64).copy())
+        return self._all_reduce(t).numpy()
+
+    def set_labels(self, y):
+        """Attach integer class labels of the resident rows (entropy criterion)."""
+        self._y = None if y is None else np.ascontiguousarray(y, dtype=np.int32)
+
+    def quantization_error(self, W) -> float:
+        dist, _ = self.bmu(W, 1)
+        s = self._reduce_host(np.array([dist.sum(), dist.size], dtype=np.float64))
+        return float(s[0] / s[1])
+
+    def topographic_error_count(self, W, coords) -> int:
+        _, idx = self.bmu(W, 2)
+        pos = np.asarray(coords, dtype=np.float64)
+        apart = np.linalg.norm(pos[idx[:, 0]] - pos[idx[:, 1]], axis=1) > 1.5
+        return int(round(self._reduce_host(np.array([np.count_nonzero(apart)], np.float64))[0]))
+
+    def node_statistics(self, W, sigma):
+        """-> (hit_counts (M,), density_sums (M,)) of BaseSom._calculate_node_statistics."""
+        dist, win = self.bmu(W, 1)
+        m = np.asarray(W).shape[0]
+        terms = np.exp(-(dist ** 2) / (2 * sigma ** 2)) / (sigma * np.sqrt(2 * np.pi))
+        both = np.concatenate([np.bincount(win, minlength=m).astype(np.float64),
+                               np.bincount(win, weights=terms, minlength=m)])
+        both = self._reduce_host(both)
+        return both[:m], both[m:]
+
+    def class_histogram(self, winners, n_classes, M):
+        h = np.zeros((M, n_classes), dtype=np.float64)
+        np.add.at(h, (winners, self._y), 1.0)
+        return self._reduce_host(h.reshape(-1)).reshape(M, n_classes).astype(np.int64)
 
     def release(self):
         pass
@@ -303,6 +350,7 @@ class HipBackend(HotPathBackend):
         dist, idx = self._bmu_dev(self._X, self._xx, self._x_np_dtype, Wd, wwd, 1, rf)
         dist, idx = dist.view(-1), idx.view(-1)
         kw = self._exp_similarity_dev(dist, gamma)
+        self._last_idx = idx
         sums = self._accumulate_dev(idx, kw, dist, Wd.shape[0])
         if want_assignments:
             return sums, idx.cpu().numpy(), dist.cpu().numpy()
@@ -327,16 +375,81 @@ class HipBackend(HotPathBackend):
         return self._hop_dev
 
     def epoch(self, W, hop, sigma, gamma, layout="compact", want_assignments=False,
-              keep_on_device=False):
+              keep_on_device=False, n_classes=0):
         """One hot-path epoch.  `W` may be a NumPy array or the `new_weights_dev` tensor of the
         previous epoch; with `keep_on_device` the new prototypes stay in HBM (no PCIe round trip
         between epochs of a phase without growth) and only the O(M) statistics come back."""
         sums, win, dist = self._local_sums(W, gamma, want_assignments)
         sums = self._all_reduce(sums)
         Wn, chg, E, a = self._smooth(sums, W, hop, sigma, layout, keep_on_device)
-        if keep_on_device:
-            return EpochResult(None, chg, E, a, win, dist, Wn)
-        return EpochResult(Wn, chg, E, a, win, dist)
+        res = (EpochResult(None, chg, E, a, win, dist, Wn) if keep_on_device
+               else EpochResult(Wn, chg, E, a, win, dist))
+        if n_classes > 0:
+            res.class_hist = self._class_hist_dev(self._last_idx, n_classes, Wn.shape[0])
+        self._last_idx = None
+        return res
+
+    # -- f-2 / f-3: reductions that keep the N-sized arrays in HBM -----------------------------
+    def _bmu_resident_dev(self, W, k):
+        self._require_loaded()
+        Wd, rf = self._as_dev_weights(W)
+        wwd = self._norms(Wd, _native.F64, Wd.shape[0], Wd.shape[1])
+        return self._bmu_dev(self._X, self._xx, self._x_np_dtype, Wd, wwd, k, rf)
+
+    def _sum_dev(self, v):
+        torch = self._torch
+        out = torch.empty(1, dtype=torch.float64, device=self.device)
+        ws = self._buf("sum", self._lib.dbgsom_sum_workspace_bytes())
+        _native.call("dbgsom_sum_f64", self._p(v), v.numel(), self._p(out), self._p(ws),
+                     ws.numel(), self._stream())
+        return out
+
+    def quantization_error(self, W) -> float:
+        dist, _ = self._bmu_resident_dev(W, 1)
+        t = self._torch.cat([self._sum_dev(dist.view(-1)),
+                             self._torch.tensor([float(dist.numel())], dtype=self._torch.float64,
+                                                device=self.device)])
+        t = self._all_reduce(t).cpu().numpy()
+        return float(t[0] / t[1])
+
+    def topographic_error_count(self, W, coords) -> int:
+        torch = self._torch
+        _, idx = self._bmu_resident_dev(W, 2)
+        xy = torch.from_numpy(np.ascontiguousarray(coords, dtype=np.int32)).to(self.device)
+        cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+        _native.call("dbgsom_topographic_count", self._p(idx), idx.shape[0], self._p(xy),
+                     xy.shape[0], self._p(cnt), self._stream())
+        return int(self._all_reduce(cnt.double()).item())
+
+    def node_statistics(self, W, sigma):
+        torch = self._torch
+        dist, idx = self._bmu_resident_dev(W, 1)
+        dist, idx = dist.view(-1), idx.view(-1)
+        terms = torch.empty_like(dist)
+        _native.call("dbgsom_density_terms", self._p(dist), dist.numel(), float(sigma),
+                     self._p(terms), self._stream())
+        M = np.asarray(W).shape[0] if not torch.is_tensor(W) else W.shape[0]
+        d = self._X.shape[1]
+        sums = self._accumulate_dev(idx, terms, dist, M)   # K = density sums, a = hit counts
+        tail = self._all_reduce(sums[M * d:M * d + 2 * M].clone()).cpu().numpy()
+        return tail[M:2 * M].copy(), tail[:M].copy()
+
+    def set_labels(self, y):
+        super().set_labels(y)
+        self._y_dev = None if y is None else self._torch.from_numpy(self._y).to(self.device)
+
+    def _class_hist_dev(self, idx_dev, n_classes, M):
+        torch = self._torch
+        if getattr(self, "_y_dev", None) is None:
+            raise RuntimeError("class histogram requested but no labels attached (set_labels)")
+        hist = torch.empty((M, n_classes), dtype=torch.int64, device=self.device)
+        _native.call("dbgsom_class_histogram", self._p(idx_dev), idx_dev.numel(),
+                     self._p(self._y_dev), M, n_classes, self._p(hist), self._stream())
+        return self._all_reduce(hist.double()).cpu().numpy().astype(np.int64)
+
+    def class_histogram(self, winners, n_classes, M):
+        idx = self._torch.from_numpy(np.ascontiguousarray(winners, dtype=np.int64)).to(self.device)
+        return self._class_hist_dev(idx, n_classes, M)
 
     def _smooth(self, sums, W, hop, sigma, layout, keep_on_device=False):
         torch = self._torch

@@ -195,6 +195,11 @@ class BaseSom(BaseEstimator):
 
             epochs = tqdm(iterable=epochs, unit=" epochs")
         need_assign = self.growth_criterion == "entropy"
+        n_classes = 0
+        if need_assign:
+            lo, hi = self._shard
+            engine.set_labels(y[lo:hi])
+            n_classes = int(self.classes_.shape[0])
         # In the fine phase the lattice no longer changes: the prototypes then stay in HBM from
         # one epoch to the next and come back to the host once, at the end.
         can_chain = hasattr(engine, "load_device")
@@ -211,7 +216,8 @@ class BaseSom(BaseEstimator):
                 w_in = w_dev
 
             res = engine.epoch(w_in, self._distance_matrix, self._calculate_current_sigma(),
-                               self._gamma(), self.centres_layout, want_assignments=need_assign,
+                               self._gamma(), self.centres_layout,
+                               n_classes=n_classes if need_assign else 0,
                                **({"keep_on_device": True} if chain else {}))
             if chain:
                 w_dev_prev, w_dev = w_in, res.new_weights_dev
@@ -219,9 +225,10 @@ class BaseSom(BaseEstimator):
                 lat.set_weights(res.new_weights)  # like the reference: the graph moves on, the
             if res.change_total < self.convergence_treshold:  # weights_ snapshot stays (Q3)
                 self.converged_ = True
-            if need_assign:
-                winners = self._gather_rows(res.winners)
-                lat.set_errors(self._entropy_errors(winners, y))
+            if need_assign:  # label entropy per neuron from the (M, n_classes) histogram
+                lat.set_errors(np.array([scipy.stats.entropy(row[: np.flatnonzero(row).max() + 1]
+                                                             if row.any() else row[:0], base=2)
+                                         for row in res.class_hist]))
             else:
                 lat.set_errors(res.errors)
 
@@ -312,13 +319,16 @@ class BaseSom(BaseEstimator):
     def calculate_quantization_error(self, X) -> float:
         """Average distance from each sample to its nearest prototype."""
         check_is_fitted(self)
-        if not self._is_resident(X):
-            X = check_array(X)
+        if self._is_resident(X):  # during fit: a device reduction, distances never leave HBM
+            return self._engine().quantization_error(self.weights_)
+        X = check_array(X)
         distances, _ = self._get_winning_neurons(X, n_bmu=1)
         return float(np.mean(distances))
 
     def _calculate_topographic_error(self, X) -> float:
         """Fraction of samples whose two best matching units are not lattice neighbours."""
+        if self._is_resident(X):
+            return self._engine().topographic_error_count(self.weights_, self.neurons_) / X.shape[0]
         _, bmu = self._get_winning_neurons(X, n_bmu=2)
         pos = np.asarray(self.neurons_, dtype=np.float64)
         apart = np.linalg.norm(pos[bmu[:, 0]] - pos[bmu[:, 1]], axis=1) > 1.5
@@ -332,14 +342,19 @@ class BaseSom(BaseEstimator):
         return scipy.spatial.distance.cdist(lat.W, lat.W[nbr_rows]).mean(axis=1)
 
     def _calculate_node_statistics(self, X):
-        distances, winners = self._get_winning_neurons(X, n_bmu=1)
         average_distances = self._get_u_matrix()
         sigma = average_distances.mean()
         m = len(self._lattice)  # neurons inserted in the very last epoch count as dead
-        hit_counts = np.bincount(winners, minlength=m).astype(np.float64)
-        dens = np.exp(-(distances ** 2) / (2 * sigma ** 2)) / (sigma * sqrt(2 * pi))
-        sums = np.bincount(winners, weights=dens, minlength=m)
-        densities = np.divide(sums, hit_counts, out=np.zeros(m), where=hit_counts > 0)
+        if self._is_resident(X):
+            hits, sums = self._engine().node_statistics(self.weights_, sigma)
+        else:
+            distances, winners = self._get_winning_neurons(X, n_bmu=1)
+            hits = np.bincount(winners, minlength=len(self.weights_)).astype(np.float64)
+            dens = np.exp(-(distances ** 2) / (2 * sigma ** 2)) / (sigma * sqrt(2 * pi))
+            sums = np.bincount(winners, weights=dens, minlength=len(self.weights_))
+        hit_counts, dens_sums = np.zeros(m), np.zeros(m)
+        hit_counts[: len(hits)], dens_sums[: len(sums)] = hits, sums
+        densities = np.divide(dens_sums, hit_counts, out=np.zeros(m), where=hit_counts > 0)
         return average_distances, densities, hit_counts
 
     def _write_node_statistics(self, X) -> None:

@@ -1,0 +1,150 @@
+// Post-fit consumers of the BMU step as device reductions: the N-sized
+// winners / distances never leave HBM.
+//
+// Replaces host loops of the reference (dbgsom/BaseSom.py):
+//   calculate_quantization_error   :904-922   mean BMU distance          -> sum_f64
+//   _calculate_topographic_error   :924-953   Python loop over N samples -> topographic_count
+//   _calculate_node_statistics     :181-211   O(N*M) boolean masks       -> density_terms + accumulate
+//   entropy criterion / _label_prototypes  :547-551, SomClassifier.py:130-152 -> class_histogram
+#include <math.h>
+
+#include "common.h"
+
+namespace dbgsom {
+
+constexpr int RB = 1024;  // partial sums (fixed -> the reduction tree does not depend on N)
+
+__global__ __launch_bounds__(256) void sum_partial_kernel(const double *__restrict__ v, int64_t n,
+                                                          double *__restrict__ part) {
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < n; i += (int64_t)RB * 256) s += v[i];
+    red[t] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(RB) void sum_final_kernel(const double *__restrict__ part,
+                                                       double *__restrict__ out) {
+    __shared__ double red[RB];
+    const int t = threadIdx.x;
+    red[t] = part[t];
+    __syncthreads();
+    for (int w = RB / 2; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) out[0] = red[0];
+}
+
+// number of samples whose two best matching units are further than 1.5 apart on the lattice
+__global__ __launch_bounds__(256) void topographic_kernel(const int64_t *__restrict__ idx2,
+                                                          int64_t n, const int32_t *__restrict__ xy,
+                                                          int M, unsigned long long *count) {
+    unsigned int local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t a = idx2[2 * i], b = idx2[2 * i + 1];
+        if (a >= 0 && a < M && b >= 0 && b < M) {
+            const double dx = (double)(xy[2 * a] - xy[2 * b]);
+            const double dy = (double)(xy[2 * a + 1] - xy[2 * b + 1]);
+            local += (sqrt(dx * dx + dy * dy) > 1.5) ? 1u : 0u;
+        }
+    }
+    // integer adds: exact and order independent
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, (unsigned long long)local);
+}
+
+__global__ void density_kernel(const double *__restrict__ dist, int64_t n, double sigma,
+                               double *__restrict__ out) {
+    const double two_s2 = 2.0 * (sigma * sigma);
+    const double norm = sigma * sqrt(2.0 * M_PI);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const double dd = dist[i];
+        out[i] = exp(-(dd * dd) / two_s2) / norm;
+    }
+}
+
+__global__ __launch_bounds__(256) void class_hist_kernel(const int64_t *__restrict__ win,
+                                                         const int32_t *__restrict__ y, int64_t n,
+                                                         int M, int C,
+                                                         unsigned long long *__restrict__ hist) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t j = win[i];
+        const int c = y[i];
+        if (j >= 0 && j < M && c >= 0 && c < C) atomicAdd(&hist[(size_t)j * C + c], 1ull);
+    }
+}
+
+static unsigned grid_for(int64_t n) {
+    const int64_t nb = (n + 255) / 256;
+    return (unsigned)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
+}
+
+}  // namespace dbgsom
+
+using namespace dbgsom;
+
+extern "C" {
+
+size_t dbgsom_sum_workspace_bytes(void) { return (size_t)RB * sizeof(double); }
+
+int dbgsom_sum_f64(const double *v_dev, int64_t n, double *out_dev, void *workspace_dev,
+                   size_t workspace_bytes, void *stream) {
+    DBGSOM_REQUIRE(n >= 0 && out_dev && workspace_dev, "bad arguments");
+    DBGSOM_REQUIRE(n == 0 || v_dev, "null input");
+    if (workspace_bytes < (size_t)RB * sizeof(double)) {
+        set_error("dbgsom_sum_f64: workspace too small");
+        return DBGSOM_ENOMEM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    double *part = (double *)workspace_dev;
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(RB), dim3(256), 0, s, v_dev, n, part);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(RB), 0, s, part, out_dev);
+    return launch_status("sum kernels");
+}
+
+int dbgsom_topographic_count(const int64_t *idx2_dev, int64_t n, const int32_t *xy_dev, int64_t M,
+                             uint64_t *count_dev, void *stream) {
+    DBGSOM_REQUIRE(n >= 0 && M >= 1 && M <= 0x7fffffff && count_dev, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DBGSOM_HIP_CHECK(hipMemsetAsync(count_dev, 0, sizeof(uint64_t), s));
+    if (n == 0) return DBGSOM_OK;
+    DBGSOM_REQUIRE(idx2_dev && xy_dev, "null pointer");
+    hipLaunchKernelGGL(topographic_kernel, dim3(grid_for(n)), dim3(256), 0, s, idx2_dev, n, xy_dev,
+                       (int)M, (unsigned long long *)count_dev);
+    return launch_status("topographic_kernel");
+}
+
+int dbgsom_density_terms(const double *dist_dev, int64_t n, double sigma, double *out_dev,
+                         void *stream) {
+    DBGSOM_REQUIRE(n >= 0 && sigma > 0.0, "bad arguments");
+    if (n == 0) return DBGSOM_OK;
+    DBGSOM_REQUIRE(dist_dev && out_dev, "null pointer");
+    hipLaunchKernelGGL(density_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                       dist_dev, n, sigma, out_dev);
+    return launch_status("density_kernel");
+}
+
+int dbgsom_class_histogram(const int64_t *idx_dev, const int32_t *y_dev, int64_t n, int64_t M,
+                           int64_t n_classes, uint64_t *hist_dev, void *stream) {
+    DBGSOM_REQUIRE(n >= 0 && M >= 1 && M <= 0x7fffffff && n_classes >= 1 &&
+                       n_classes <= 0x7fffffff && hist_dev, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DBGSOM_HIP_CHECK(hipMemsetAsync(hist_dev, 0, (size_t)M * n_classes * sizeof(uint64_t), s));
+    if (n == 0) return DBGSOM_OK;
+    DBGSOM_REQUIRE(idx_dev && y_dev, "null pointer");
+    hipLaunchKernelGGL(class_hist_kernel, dim3(grid_for(n)), dim3(256), 0, s, idx_dev, y_dev, n,
+                       (int)M, (int)n_classes, (unsigned long long *)hist_dev);
+    return launch_status("class_hist_kernel");
+}
+
+}  // extern "C"

@@ -108,6 +108,32 @@ int dbgsom_smooth(const double *sums_dev, int64_t M, int64_t d, const float *hop
                   double *change_total_dev, void *workspace_dev, size_t workspace_bytes,
                   void *stream);
 
+/* ---- post-fit consumers of the BMU step as device reductions (N-sized arrays stay in HBM) ---- */
+
+/* out[0] = sum of v[0..n) with a fixed reduction tree (bitwise reproducible).  Mean BMU distance =
+ * BaseSom.calculate_quantization_error  BaseSom.py:904-922. */
+size_t dbgsom_sum_workspace_bytes(void);
+int dbgsom_sum_f64(const double *v_dev, int64_t n, double *out_dev, void *workspace_dev,
+                   size_t workspace_bytes, void *stream);
+
+/* count of samples whose two BMUs (idx2: n x 2 from dbgsom_bmu with k=2) are further than 1.5
+ * apart on the lattice; xy: M x 2 int32 neuron coordinates.
+ * BaseSom._calculate_topographic_error  BaseSom.py:924-953 (its Python loop over the samples). */
+int dbgsom_topographic_count(const int64_t *idx2_dev, int64_t n, const int32_t *xy_dev, int64_t M,
+                             uint64_t *count_dev, void *stream);
+
+/* out_i = exp(-dist_i^2 / (2 sigma^2)) / (sigma sqrt(2 pi)): the per-sample term of the local
+ * density estimate, BaseSom._calculate_node_statistics BaseSom.py:203-206.  Feeding it to
+ * dbgsom_accumulate as `kw` yields per-neuron density sums (K) and hit counts (a). */
+int dbgsom_density_terms(const double *dist_dev, int64_t n, double sigma, double *out_dev,
+                         void *stream);
+
+/* hist[j, c] = |{i : win_i = j, y_i = c}| (M x n_classes uint64, integer atomics: exact).
+ * Entropy growth criterion BaseSom.py:547-551 and SomClassifier._label_prototypes
+ * SomClassifier.py:130-152 (their O(N*M) boolean masks). */
+int dbgsom_class_histogram(const int64_t *idx_dev, const int32_t *y_dev, int64_t n, int64_t M,
+                           int64_t n_classes, uint64_t *hist_dev, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Context-level entry points (host pointers; the library owns the device memory).
  * This is the seam a NumPy caller such as the reference binds with ctypes: X is uploaded once

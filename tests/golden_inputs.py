@@ -27,6 +27,11 @@ def case_X(name):
 
         dg = load_digits()
         return dg.data, (dg.target if name == "digits_clf" else None)
+    if name == "digits_entropy":
+        from sklearn.datasets import load_digits
+
+        dg = load_digits()
+        return dg.data[:900], dg.target[:900]
     if name == "digits_f32":
         from sklearn.datasets import load_digits
 
@@ -50,7 +55,9 @@ def case_X(name):
     raise KeyError(name)
 
 
-FIT_CASES = ["digits_f64", "digits_f32", "blobs_dead", "lowd_linear", "ties_int", "digits_clf"]
+FIT_CASES = ["digits_f64", "digits_f32", "blobs_dead", "lowd_linear", "ties_int", "digits_clf",
+             "digits_entropy"]
+CLF_CASES = ("digits_clf", "digits_entropy")
 FROZEN_CASES = ["frozen_c2_f32", "frozen_c3_f32", "frozen_f64"]
 
 EST_KWARGS = {
@@ -63,6 +70,8 @@ EST_KWARGS = {
                         spreading_factor=0.3, sigma_start=2.0, sigma_end=0.5,
                         coarse_training_frac=0.6, convergence_iter=3),
     "ties_int": dict(random_state=1, n_iter=12, max_neurons=30),
+    "digits_entropy": dict(random_state=0, n_iter=30, growth_criterion="entropy",
+                           spreading_factor=0.4, max_neurons=40),
 }
 
 

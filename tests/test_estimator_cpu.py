@@ -18,8 +18,8 @@ class TracingBackend(OracleBackend):
         super().__init__(bmu)
         self.trace = []
 
-    def epoch(self, W, hop, sigma, gamma, layout="compact", want_assignments=False):
-        res = super().epoch(W, hop, sigma, gamma, layout, want_assignments)
+    def epoch(self, W, hop, sigma, gamma, layout="compact", want_assignments=False, **kw):
+        res = super().epoch(W, hop, sigma, gamma, layout, want_assignments, **kw)
         self.trace.append((np.asarray(W).shape[0], float(sigma), float(res.new_weights.sum()),
                            res.change_total, int((res.activations == 0).sum())))
         return res
@@ -28,7 +28,7 @@ class TracingBackend(OracleBackend):
 def _fit(name):
     X, y = gi.case_X(name)
     be = TracingBackend()
-    cls = SomClassifier if name == "digits_clf" else SomVQ
+    cls = SomClassifier if name in gi.CLF_CASES else SomVQ
     est = cls(backend=be, **gi.EST_KWARGS[name])
     est.fit(X, y) if y is not None else est.fit(X)
     return est, be, X, y
@@ -63,7 +63,7 @@ def test_full_fit_matches_reference(name):
                                rtol=1e-9, atol=1e-9)
     assert np.array_equal([d["epoch_created"] for _, d in est.som_.nodes.data()],
                           g["final_epoch_created"])
-    if name != "digits_clf":
+    if name not in gi.CLF_CASES:
         assert np.array_equal(est.labels_, g["final_labels"])
         assert np.array_equal(est.predict(X), g["final_labels"])
     else:
@@ -84,9 +84,9 @@ def test_growth_trace_node_by_node():
     seen = []
 
     class B(OracleBackend):
-        def epoch(self, W, hop, sigma, gamma, layout="compact", want_assignments=False):
+        def epoch(self, W, hop, sigma, gamma, layout="compact", want_assignments=False, **kw):
             seen.append(hop.shape[0])
-            return super().epoch(W, hop, sigma, gamma, layout, want_assignments)
+            return super().epoch(W, hop, sigma, gamma, layout, want_assignments, **kw)
 
     est = SomVQ(backend=B(), **gi.EST_KWARGS["blobs_dead"])
     # follow neurons_ every epoch through the verbose-free loop: re-run with a hook on sigma

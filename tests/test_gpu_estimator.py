@@ -15,7 +15,7 @@ def test_fit_on_gpu_matches_reference(name):
 
     g = gi.load(name)
     X, y = gi.case_X(name)
-    cls = SomClassifier if name == "digits_clf" else SomVQ
+    cls = SomClassifier if name in gi.CLF_CASES else SomVQ
     est = cls(**gi.EST_KWARGS[name])  # backend=None -> HipBackend
     est.fit(X, y) if y is not None else est.fit(X)
     assert isinstance(est._engine(), HipBackend)
@@ -25,7 +25,7 @@ def test_fit_on_gpu_matches_reference(name):
     np.testing.assert_allclose(est.weights_, g["final_weights"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(est.quantization_error_, float(g["final_qe"]), rtol=1e-10)
     assert est.topographic_error_ == float(g["final_te"])
-    if name != "digits_clf":
+    if name not in gi.CLF_CASES:
         assert np.array_equal(est.labels_, g["final_labels"])   # BMU indices bit-exact
         assert np.array_equal(est.predict(X), g["final_labels"])
         assert np.array_equal(cls(**gi.EST_KWARGS[name]).fit_predict(X), g["final_labels"])

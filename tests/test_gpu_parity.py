@@ -114,7 +114,8 @@ def test_golden_epochs(hip, o, name):
         np.testing.assert_allclose(res.distances ** 2, g[f"e{e}_distances"] ** 2,
                                    rtol=1e-7 if W.dtype == np.float32 else 1e-9, atol=1e-12 * xn)
         assert np.array_equal(res.activations, g[f"e{e}_activations"])
-        np.testing.assert_allclose(res.errors, g[f"e{e}_errors"], rtol=1e-9, atol=1e-6)
+        if f"e{e}_errors" in g:
+            np.testing.assert_allclose(res.errors, g[f"e{e}_errors"], rtol=1e-9, atol=1e-6)
         np.testing.assert_allclose(res.new_weights, g[f"e{e}_weights_out"], rtol=1e-7, atol=1e-9,
                                    equal_nan=True)
         # against the oracle on the same inputs: tight
@@ -286,3 +287,35 @@ def test_full_size_properties(hip, o):
     p = perm.cpu().numpy()
     assert np.array_equal(i2, win[p]) and np.array_equal(d2, dist[p])
     hip.release()
+
+
+def test_device_reductions_f2_f3(hip, o):
+    """QE / TE / hit counts / densities / class histogram as device
+    reductions against the host statements."""
+    rng = np.random.default_rng(17)
+    N, d, rows, cols, C = 7001, 24, 6, 7, 5
+    M = rows * cols
+    X = rng.normal(size=(N, d)).astype(np.float32)
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    W[5] += 40.0  # a dead neuron
+    y = rng.integers(0, C, size=N).astype(np.int32)
+    hip.load(X)
+    hip.set_labels(y)
+    dist, win = o.bmu_chain(X, W, 1)
+    _, idx2 = o.bmu_chain(X, W, 2)
+    np.testing.assert_allclose(hip.quantization_error(W), dist.mean(), rtol=1e-13)
+    coords = [(i, j) for i in range(rows) for j in range(cols)]
+    pos = np.asarray(coords, dtype=np.float64)
+    te = int((np.linalg.norm(pos[idx2[:, 0]] - pos[idx2[:, 1]], axis=1) > 1.5).sum())
+    assert hip.topographic_error_count(W, coords) == te
+    sigma = 1.7
+    hits, dens = hip.node_statistics(W, sigma)
+    assert np.array_equal(hits, np.bincount(win, minlength=M))
+    terms = np.exp(-(dist ** 2) / (2 * sigma ** 2)) / (sigma * np.sqrt(2 * np.pi))
+    np.testing.assert_allclose(dens, np.bincount(win, weights=terms, minlength=M), rtol=1e-12,
+                               atol=1e-300)
+    ref = np.zeros((M, C), dtype=np.int64)
+    np.add.at(ref, (win, y), 1)
+    assert np.array_equal(hip.class_histogram(win, C, M), ref)
+    res = hip.epoch(W, gi.lattice_hops(rows, cols), 1.0, 0.01, "compact", n_classes=C)
+    assert np.array_equal(res.class_hist, ref)

@@ -36,7 +36,8 @@ def test_hot_path_per_epoch(name):
         kw = g[f"e{e}_sample_weights"]
         S, K, a, E = o.accumulate(X, gw, kw, gd, M)
         assert np.array_equal(a, g[f"e{e}_activations"])
-        np.testing.assert_allclose(E, g[f"e{e}_errors"], rtol=1e-12)
+        if f"e{e}_errors" in g:
+            np.testing.assert_allclose(E, g[f"e{e}_errors"], rtol=1e-12)
         C = o.voronoi_centers(S, K, a, "compact")  # quirk Q1
         np.testing.assert_allclose(C, g[f"e{e}_centers_compact"], rtol=1e-11, atol=1e-12)
         S2, K2, a2, E2 = o.accumulate_numpy(X, gw, kw, gd, M)
@@ -84,7 +85,7 @@ def test_bmu_k2_on_fitted_map(name):
             assert np.array_equal(np.sort(i[bad], axis=1), np.sort(gidx[bad], axis=1)) or \
                 np.allclose(d[bad, 0], d[bad, 1], rtol=1e-12)
     d1, i1 = o.bmu_chain(X, W, 1)
-    assert np.array_equal(i1, g["final_labels"]) or name == "digits_clf"
+    assert np.array_equal(i1, g["final_labels"]) or name in gi.CLF_CASES
 
 
 @pytest.mark.parametrize("name", gi.FROZEN_CASES)

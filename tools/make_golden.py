@@ -150,7 +150,8 @@ class Recorder:
         out = {}
         for e, d in self.full.items():
             for k, v in d.items():
-                out[f"e{e}_{k}"] = v
+                if v is not None:  # (no numba error sum under the entropy criterion)
+                    out[f"e{e}_{k}"] = v
         out["epochs_full"] = np.array(sorted(self.full), dtype=np.int64)
         for k in ("n_neurons", "sigma", "weights_sum", "change_total", "n_dead", "phase_fine"):
             out[f"trace_{k}"] = np.array(self.trace[k])
@@ -321,9 +322,30 @@ def run_frozen_case(name, X, rows, cols, seed, wdtype):
 
 
 def main():
+    only = set(sys.argv[1:])
+    mpath = os.path.join(OUT, "manifest.json")
     manifest = {"versions": ref_shim.versions(), "cases": {}}
+    if only and os.path.exists(mpath):
+        manifest = json.load(open(mpath))
     digits = load_digits()
     Xd = digits.data  # float64, integer valued 0..16 (exact-tie prone, SURVEY hard part 1)
+
+    if not only or "digits_entropy" in only:
+        # supervised growth criterion: per-neuron label entropy (BaseSom.py:547-551)
+        manifest["cases"]["digits_entropy"] = run_fit_case(
+            "digits_entropy",
+            lambda: SomClassifier(random_state=0, n_iter=30, growth_criterion="entropy",
+                                  spreading_factor=0.4, max_neurons=40),
+            Xd[:900], digits.target[:900], [0, 5, 29],
+            {"X": "load_digits() data/target [:900]",
+             "est": "SomClassifier(random_state=0, n_iter=30, growth_criterion='entropy', "
+                    "spreading_factor=0.4, max_neurons=40)"},
+        )
+    if only:
+        with open(mpath, "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        print("done (subset)")
+        return
 
     manifest["cases"]["digits_f64"] = run_fit_case(
         "digits_f64", lambda: SomVQ(random_state=0), Xd, None, [0, 1, 7, 50, 111],

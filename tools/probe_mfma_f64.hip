@@ -62,7 +62,7 @@ int main() {
     printf("mfma_f64_16x16x4 vs host models over 200x256 outputs: mismatches  fma-chain k0..3: %d  reversed: %d  pairwise: %d  unfused: %d\n",
            bad_chain, bad_rev, bad_pair, bad_nofma);
     // issue rate: 8 independent accumulators per wave, 4 waves per block (1 per SIMD), 256*2 blocks
-    const int iters = 20000, blocks = 512;
+    const int iters = 400000, blocks = 512;
     double *dout; hipMalloc(&dout, blocks * 256 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(rate, dim3(blocks), dim3(256), 0, 0, dout, 100);
