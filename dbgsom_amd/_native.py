@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdbgsom_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "dbgsom_hip.h")
 
-F32, F64 = 0, 1
+F32, F64, BF16 = 0, 1, 2
 CENTRES_COMPACT, CENTRES_ALIGNED = 0, 1
 LAYOUTS = {"compact": CENTRES_COMPACT, "aligned": CENTRES_ALIGNED}
 MAX_PROTOTYPES = 16000

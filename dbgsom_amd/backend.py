@@ -159,6 +159,8 @@ class HotPathBackend:
 
 
 def _x_dtype_code(dt) -> int:
+    if dt == "bf16":
+        return _native.BF16
     if dt == np.float32:
         return _native.F32
     if dt == np.float64:
@@ -239,26 +241,36 @@ class HipBackend(HotPathBackend):
     def _round_f32(self, W, xdtype):
         # float32 samples AND float32 prototypes: the reference's engine returns float32-rounded
         # distances (epoch 0 of a float32 fit).  Every other mix is full float64.
-        return int(xdtype == np.float32 and np.asarray(W).dtype == np.float32)
+        return int((not isinstance(xdtype, str)) and xdtype == np.float32
+                   and np.asarray(W).dtype == np.float32)
 
     # -- a8: residency --------------------------------------------------------------------------
-    def load(self, X):
+    def load(self, X, storage=None):
+        """Upload the samples once.  `storage="bf16"` keeps them in HBM as bfloat16 (rounded to
+        nearest even on the device; all arithmetic stays float64 on the exactly widened values --
+        an extension, the reference has no bf16)."""
         X = np.ascontiguousarray(X)
         code = _x_dtype_code(X.dtype)
         if X.ndim != 2 or X.shape[0] < 1:
             raise ValueError("X must be a non-empty 2-D array")
+        Xd = self._torch.from_numpy(X).to(self.device)
+        if storage == "bf16":
+            return self.load_device(Xd.to(self._torch.bfloat16))
+        if storage not in (None, "native"):
+            raise ValueError("storage must be None or 'bf16'")
         self._x_np_dtype = X.dtype
-        self._X = self._torch.from_numpy(X).to(self.device)
+        self._X = Xd
         self._xx = self._norms(self._X, code, X.shape[0], X.shape[1])
         return self
 
     def load_device(self, X_dev):
         """Adopt samples that already live in HBM (bench: generated on the device)."""
         torch = self._torch
-        if X_dev.dtype not in (torch.float32, torch.float64) or X_dev.dim() != 2:
-            raise ValueError("X_dev must be a 2-D float32/float64 tensor")
+        if X_dev.dtype not in (torch.float32, torch.float64, torch.bfloat16) or X_dev.dim() != 2:
+            raise ValueError("X_dev must be a 2-D float32/float64/bfloat16 tensor")
         X_dev = X_dev.contiguous()
-        self._x_np_dtype = np.dtype(np.float32 if X_dev.dtype == torch.float32 else np.float64)
+        self._x_np_dtype = {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64),
+                            torch.bfloat16: "bf16"}[X_dev.dtype]
         self._X = X_dev
         self._xx = self._norms(X_dev, _x_dtype_code(self._x_np_dtype), X_dev.shape[0],
                                X_dev.shape[1])

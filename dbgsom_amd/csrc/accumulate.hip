@@ -167,6 +167,28 @@ __global__ __launch_bounds__(AT) void scatter_kernel(const int64_t *__restrict__
     }
 }
 
+template <typename XT, int VEC>
+__device__ __forceinline__ void load_vec(const XT *__restrict__ src, double (&v)[VEC]) {
+    if constexpr (sizeof(XT) == 4 && VEC == 4) {
+        const float4 t4 = *reinterpret_cast<const float4 *>(src);
+        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+    } else if constexpr (sizeof(XT) == 8 && VEC == 2) {
+        const double2 t2 = *reinterpret_cast<const double2 *>(src);
+        v[0] = t2.x; v[1] = t2.y;
+    } else if constexpr (sizeof(XT) == 2 && VEC == 8) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(src);
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = (double)__uint_as_float(w[e] << 16);
+            v[2 * e + 1] = (double)__uint_as_float(w[e] & 0xffff0000u);
+        }
+    } else {
+        static_assert(VEC == 1, "unsupported vector width");
+        v[0] = widen(src[0]);
+    }
+}
+
 // ---- 5. one workgroup sums one chunk (<= CH rows of one neuron) in list order ----------------
 template <typename XT, int VEC>
 __global__ __launch_bounds__(AT) void segsum_kernel(
@@ -219,12 +241,10 @@ __global__ __launch_bounds__(AT) void segsum_kernel(
             for (int p = 0; p < n; ++p) {
                 const XT *src = X + (int64_t)rows_s[p] * ldx + (int64_t)q * VEC;
                 const double w = kw_s[p];
-                XT v[VEC];
-                if constexpr (VEC == 4) { const float4 t4 = *reinterpret_cast<const float4 *>(src); v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w; }
-                else if constexpr (VEC == 2) { const double2 t2 = *reinterpret_cast<const double2 *>(src); v[0] = t2.x; v[1] = t2.y; }
-                else { v[0] = src[0]; }
+                double v[VEC];
+                load_vec<XT, VEC>(src, v);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] += w * (double)v[e];
+                for (int e = 0; e < VEC; ++e) acc[e] += w * v[e];
             }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) out[q * VEC + e] = acc[e];
@@ -240,12 +260,10 @@ __global__ __launch_bounds__(AT) void segsum_kernel(
             for (int p = rl; p < n; p += RL) {
                 const XT *src = X + (int64_t)rows_s[p] * ldx + (int64_t)q * VEC;
                 const double w = kw_s[p];
-                XT v[VEC];
-                if constexpr (VEC == 4) { const float4 t4 = *reinterpret_cast<const float4 *>(src); v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w; }
-                else if constexpr (VEC == 2) { const double2 t2 = *reinterpret_cast<const double2 *>(src); v[0] = t2.x; v[1] = t2.y; }
-                else { v[0] = src[0]; }
+                double v[VEC];
+                load_vec<XT, VEC>(src, v);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] += w * (double)v[e];
+                for (int e = 0; e < VEC; ++e) acc[e] += w * v[e];
             }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) red[(rl * Q + q) * VEC + e] = acc[e];
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(AT) void finalize_kernel(const double *__restrict__
 int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                       const int64_t *idx, const double *kw, const double *dist, int64_t M,
                       double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s) {
-    DBGSOM_REQUIRE(x_dtype == DBGSOM_F32 || x_dtype == DBGSOM_F64, "x_dtype must be DBGSOM_F32/F64");
+    DBGSOM_REQUIRE(valid_dtype(x_dtype), "x_dtype must be DBGSOM_F32/F64/BF16");
     DBGSOM_REQUIRE(N >= 0 && N < 0x7fffffff && d >= 1 && d <= 0x7ffffff0 && ldx >= d, "bad sample shape");
     DBGSOM_REQUIRE(M >= 1 && M <= DBGSOM_MAX_PROTOTYPES, "M outside [1, DBGSOM_MAX_PROTOTYPES]");
     DBGSOM_REQUIRE(sums, "null sums");
@@ -322,7 +340,7 @@ int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t 
     hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)w.nb), dim3(AT), (size_t)M * 4, s,
                        idx, N, Mi, w.blk, w.seg_start, w.order);
 
-    const size_t xe = (x_dtype == DBGSOM_F32) ? 4 : 8;
+    const size_t xe = dtype_size(x_dtype);
     const bool al16 = is_aligned(X, 16) && ((ldx * xe) % 16 == 0);
     dim3 grid((unsigned)w.maxchunks), block(AT);
 #define DBGSOM_SEGSUM(XT, V)                                                                    \
@@ -330,8 +348,10 @@ int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t 
                        kw, dist, w.seg_start, w.count, w.chunk_pre, Mi, w.slab)
     if (x_dtype == DBGSOM_F32) {
         if (al16 && d % 4 == 0) DBGSOM_SEGSUM(float, 4); else DBGSOM_SEGSUM(float, 1);
-    } else {
+    } else if (x_dtype == DBGSOM_F64) {
         if (al16 && d % 2 == 0) DBGSOM_SEGSUM(double, 2); else DBGSOM_SEGSUM(double, 1);
+    } else {
+        if (al16 && d % 8 == 0) DBGSOM_SEGSUM(bf16_t, 8); else DBGSOM_SEGSUM(bf16_t, 1);
     }
 #undef DBGSOM_SEGSUM
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)M), dim3(AT), 0, s, w.slab, di, Mi, w.count,

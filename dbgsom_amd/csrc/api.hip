@@ -157,9 +157,9 @@ int dbgsom_ctx_destroy(dbgsom_ctx *c) {
 
 int dbgsom_ctx_load(dbgsom_ctx *c, const void *X_host, int x_dtype, int64_t N, int64_t d) {
     CTX_CHECK(c);
-    DBGSOM_REQUIRE(x_dtype == DBGSOM_F32 || x_dtype == DBGSOM_F64, "x_dtype must be DBGSOM_F32/F64");
+    DBGSOM_REQUIRE(valid_dtype(x_dtype), "x_dtype must be DBGSOM_F32/F64/BF16");
     DBGSOM_REQUIRE(X_host && N >= 1 && d >= 1, "bad samples");
-    const size_t es = x_dtype == DBGSOM_F32 ? 4 : 8;
+    const size_t es = dtype_size(x_dtype);
     TRY(c->X.reserve((size_t)N * d * es));
     TRY(c->xx.reserve((size_t)N * 8));
     DBGSOM_HIP_CHECK(hipMemcpyAsync(c->X.p, X_host, (size_t)N * d * es, hipMemcpyHostToDevice,
@@ -215,11 +215,11 @@ int dbgsom_ctx_bmu_query(dbgsom_ctx *c, const void *Xq_host, int x_dtype, int64_
                          const double *W_host, int64_t M, int k, int round_f32, int64_t *idx_host,
                          double *dist_host) {
     CTX_CHECK(c);
-    DBGSOM_REQUIRE(x_dtype == DBGSOM_F32 || x_dtype == DBGSOM_F64, "x_dtype must be DBGSOM_F32/F64");
+    DBGSOM_REQUIRE(valid_dtype(x_dtype), "x_dtype must be DBGSOM_F32/F64/BF16");
     DBGSOM_REQUIRE(Xq_host && W_host && idx_host && dist_host && Nq >= 0 && d >= 1 && M >= 1 &&
                        (k == 1 || k == 2), "bad arguments");
     if (Nq == 0) return DBGSOM_OK;
-    const size_t es = x_dtype == DBGSOM_F32 ? 4 : 8;
+    const size_t es = dtype_size(x_dtype);
     DevBuf Wq, wwq, iq, dq;  // query-sized scratch; independent of the training state
     int rc = DBGSOM_OK;
     do {

@@ -39,7 +39,15 @@ __device__ __forceinline__ void load8(const T *__restrict__ base, int64_t row, i
     if (row < nrows && k < d) {
         const T *p = base + row * ld + k;
         if (vec_ok && k + 8 <= d) {
-            if constexpr (sizeof(T) == 4) {
+            if constexpr (sizeof(T) == 2) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(p);
+                const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e].bits = (uint16_t)(w[e] & 0xffffu);
+                    v[2 * e + 1].bits = (uint16_t)(w[e] >> 16);
+                }
+            } else if constexpr (sizeof(T) == 4) {
                 const float4 a = *reinterpret_cast<const float4 *>(p);
                 const float4 b = *reinterpret_cast<const float4 *>(p + 4);
                 v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
@@ -142,7 +150,8 @@ __global__ __launch_bounds__(NT, 2) void bmu_kernel(
         double *wd = &wsm[buf][lrow * LS + lk];
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
-            *reinterpret_cast<double2 *>(xd + e) = double2{(double)xr[e], (double)xr[e + 1]};
+            *reinterpret_cast<double2 *>(xd + e) =
+                double2{widen(xr[e]), widen(xr[e + 1])};
             *reinterpret_cast<double2 *>(wd + e) = double2{wr[e], wr[e + 1]};
         }
     };
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(NORM_THREADS) void row_sqnorms_kernel(const T *__re
             const int r = e / NK, c = e % NK;  // consecutive threads -> consecutive features
             const int64_t row = r0 + r;
             const int k = k0 + c;
-            tile[r][c] = (row < rows && k < d) ? (double)A[row * ld + k] : 0.0;
+            tile[r][c] = (row < rows && k < d) ? widen(A[row * ld + k]) : 0.0;
         }
         __syncthreads();
         if (tid < NR) {
@@ -325,7 +334,7 @@ __global__ void exp_similarity_kernel(const double *__restrict__ dist, int64_t N
 // ---------------------------------------------------------------------------------------------
 int launch_row_sqnorms(const void *A, int dtype, int64_t rows, int64_t d, int64_t ld, double *out,
                        hipStream_t s) {
-    DBGSOM_REQUIRE(dtype == DBGSOM_F32 || dtype == DBGSOM_F64, "dtype must be DBGSOM_F32/F64");
+    DBGSOM_REQUIRE(valid_dtype(dtype), "dtype must be DBGSOM_F32/F64/BF16");
     DBGSOM_REQUIRE(rows >= 0 && d >= 1 && ld >= d && d <= 0x7fffffff, "bad shape");
     if (rows == 0) return DBGSOM_OK;
     DBGSOM_REQUIRE(A && out, "null pointer");
@@ -337,9 +346,12 @@ int launch_row_sqnorms(const void *A, int dtype, int64_t rows, int64_t d, int64_
     if (dtype == DBGSOM_F32) {
         if (small) hipLaunchKernelGGL((row_sqnorms_kernel<float, 16, 256>), grid, block, 0, s, (const float *)A, rows, (int)d, ld, out);
         else hipLaunchKernelGGL((row_sqnorms_kernel<float, 128, 32>), grid, block, 0, s, (const float *)A, rows, (int)d, ld, out);
-    } else {
+    } else if (dtype == DBGSOM_F64) {
         if (small) hipLaunchKernelGGL((row_sqnorms_kernel<double, 16, 256>), grid, block, 0, s, (const double *)A, rows, (int)d, ld, out);
         else hipLaunchKernelGGL((row_sqnorms_kernel<double, 128, 32>), grid, block, 0, s, (const double *)A, rows, (int)d, ld, out);
+    } else {
+        if (small) hipLaunchKernelGGL((row_sqnorms_kernel<bf16_t, 16, 256>), grid, block, 0, s, (const bf16_t *)A, rows, (int)d, ld, out);
+        else hipLaunchKernelGGL((row_sqnorms_kernel<bf16_t, 128, 32>), grid, block, 0, s, (const bf16_t *)A, rows, (int)d, ld, out);
     }
     return launch_status("row_sqnorms_kernel");
 }
@@ -347,7 +359,7 @@ int launch_row_sqnorms(const void *A, int dtype, int64_t rows, int64_t d, int64_
 int launch_bmu(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx, const double *xx,
                const double *W, int64_t M, const double *ww, int k, int round_f32, int64_t *idx,
                double *dist, hipStream_t s) {
-    DBGSOM_REQUIRE(x_dtype == DBGSOM_F32 || x_dtype == DBGSOM_F64, "x_dtype must be DBGSOM_F32/F64");
+    DBGSOM_REQUIRE(valid_dtype(x_dtype), "x_dtype must be DBGSOM_F32/F64/BF16");
     DBGSOM_REQUIRE(k == 1 || k == 2, "k must be 1 or 2");
     DBGSOM_REQUIRE(N >= 0 && d >= 1 && ldx >= d && d <= 0x7fffffff, "bad sample shape");
     DBGSOM_REQUIRE(M >= k && M <= 0x7fffff00, "need k <= M < 2^31");
@@ -355,7 +367,7 @@ int launch_bmu(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx, co
     DBGSOM_REQUIRE(X && xx && W && ww && idx && dist, "null pointer");
     const int64_t nb = (N + BI - 1) / BI;
     DBGSOM_REQUIRE(nb <= 0x7fffffff, "too many samples for one launch");
-    const size_t xe = (x_dtype == DBGSOM_F32) ? 4 : 8;
+    const size_t xe = dtype_size(x_dtype);
     const int xvec = is_aligned(X, 16) && ((ldx * xe) % 16 == 0);
     const int wvec = is_aligned(W, 16) && ((d * 8) % 16 == 0);
     dim3 grid((unsigned)nb), block(NT);
@@ -364,8 +376,10 @@ int launch_bmu(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx, co
                        xx, W, (int)M, ww, round_f32, xvec, wvec, idx, dist)
     if (x_dtype == DBGSOM_F32) {
         if (k == 1) DBGSOM_BMU_LAUNCH(float, 1); else DBGSOM_BMU_LAUNCH(float, 2);
-    } else {
+    } else if (x_dtype == DBGSOM_F64) {
         if (k == 1) DBGSOM_BMU_LAUNCH(double, 1); else DBGSOM_BMU_LAUNCH(double, 2);
+    } else {
+        if (k == 1) DBGSOM_BMU_LAUNCH(bf16_t, 1); else DBGSOM_BMU_LAUNCH(bf16_t, 2);
     }
 #undef DBGSOM_BMU_LAUNCH
     return launch_status("bmu_kernel");

@@ -37,6 +37,22 @@ inline int launch_status(const char *what) {
     return DBGSOM_OK;
 }
 
+// bfloat16 storage element: the upper 16 bits of a float32; widening is exact
+struct bf16_t {
+    uint16_t bits;
+    __host__ __device__ bf16_t() = default;
+    __host__ __device__ explicit bf16_t(int) : bits(0) {}
+    __device__ __forceinline__ operator float() const { return __uint_as_float(((uint32_t)bits) << 16); }
+};
+
+// exact widening of a stored sample element to float64
+__device__ __forceinline__ double widen(double v) { return v; }
+__device__ __forceinline__ double widen(float v) { return (double)v; }
+__device__ __forceinline__ double widen(bf16_t v) { return (double)(float)v; }
+
+inline bool valid_dtype(int dt) { return dt == DBGSOM_F32 || dt == DBGSOM_F64 || dt == DBGSOM_BF16; }
+inline size_t dtype_size(int dt) { return dt == DBGSOM_F64 ? 8 : (dt == DBGSOM_F32 ? 4 : 2); }
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline bool is_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 

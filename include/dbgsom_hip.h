@@ -34,6 +34,7 @@ extern "C" {
 /* sample storage types (the reference accepts float64 and float32 input: SomVQ.py:121-124) */
 #define DBGSOM_F32 0
 #define DBGSOM_F64 1
+#define DBGSOM_BF16 2 /* storage-only extension (bfloat16 bits, exact up-cast; arithmetic stays float64) */
 
 /* layout of the Voronoi-centre rows fed to the smoothing step */
 #define DBGSOM_CENTRES_COMPACT 0 /* reference behaviour: BaseSom.py:1045,1053 (row = rank among non-empty neurons) */

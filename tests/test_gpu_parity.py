@@ -319,3 +319,29 @@ def test_device_reductions_f2_f3(hip, o):
     assert np.array_equal(hip.class_histogram(win, C, M), ref)
     res = hip.epoch(W, gi.lattice_hops(rows, cols), 1.0, 0.01, "compact", n_classes=C)
     assert np.array_equal(res.class_hist, ref)
+
+
+def _bf16_round(X):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.parametrize("N,d,M", [(3000, 256, 130), (1025, 2048, 260), (700, 13, 9)])
+def test_bf16_storage_matches_oracle_on_rounded_samples(hip, o, N, d, M):
+    """BASELINE config C5 shape (d=2048, bf16 samples), scaled: parity is against the oracle fed
+    the same bf16-rounded X (the reference has no bf16)."""
+    X, W = _rand(N, d, M, np.float32, 77 + d)
+    Xr = _bf16_round(X)
+    hip.load(X, storage="bf16")
+    rows = cols = int(np.ceil(np.sqrt(M)))
+    hop = gi.lattice_hops(rows, cols)[:M, :M]
+    res = hip.epoch(W, hop, 1.5, 1e-3, "compact", True)
+    oo = o.epoch(Xr, W, hop, 1.5, np.float64(1e3), "compact", "chain")
+    assert np.array_equal(res.winners, oo.winners)
+    assert np.array_equal(res.distances, oo.distances)
+    np.testing.assert_allclose(res.new_weights, oo.new_weights, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(res.errors, oo.errors, rtol=1e-12)
+    d2, i2 = hip.bmu(W, 2)
+    rd, ri = o.bmu_chain(Xr, W, 2)
+    assert np.array_equal(i2, ri) and np.array_equal(d2, rd)
