@@ -455,8 +455,8 @@ class HipBackend(HotPathBackend):
         if getattr(self, "_y_dev", None) is None:
             raise RuntimeError("class histogram requested but no labels attached (set_labels)")
         hist = torch.empty((M, n_classes), dtype=torch.int64, device=self.device)
-        _native.call("dbgsom_class_histogram", self._p(idx_dev), idx_dev.numel(),
-                     self._p(self._y_dev), M, n_classes, self._p(hist), self._stream())
+        _native.call("dbgsom_class_histogram", self._p(idx_dev), self._p(self._y_dev),
+                     idx_dev.numel(), M, n_classes, self._p(hist), self._stream())
         return self._all_reduce(hist.double()).cpu().numpy().astype(np.int64)
 
     def class_histogram(self, winners, n_classes, M):
