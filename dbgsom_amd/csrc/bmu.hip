@@ -20,18 +20,13 @@
 //   * epilogue: cross-lane merge with __shfl_xor (lanes l, l^16, l^32, l^48 share a sample),
 //     then the two wavefronts that share a sample merge through LDS.
 #include <math.h>
+#include <stdlib.h>
 
-#include "common.h"
+#include "bmu_common.h"
 
 namespace dbgsom {
 
-typedef double d4_t __attribute__((ext_vector_type(4)));
-
-constexpr int BI = 128;     // samples per workgroup
-constexpr int BJ = 128;     // prototypes per sweep chunk
-constexpr int KT = 16;      // feature depth of one LDS tile
 constexpr int LS = KT + 2;  // LDS row stride (doubles)
-constexpr int NT = 256;
 
 template <typename T>
 __device__ __forceinline__ void load8(const T *__restrict__ base, int64_t row, int64_t nrows,
@@ -69,47 +64,6 @@ __device__ __forceinline__ void load8(const T *__restrict__ base, int64_t row, i
         for (int e = 0; e < 8; ++e) v[e] = T(0);
     }
 }
-
-__device__ __forceinline__ bool lex_lt(double a, int ja, double b, int jb) {
-    return a < b || (a == b && ja < jb);
-}
-
-template <int K>
-struct Best {
-    double v[K];
-    int j[K];
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int t = 0; t < K; ++t) { v[t] = INFINITY; j[t] = 0x7fffffff; }
-    }
-    // candidates arrive with ascending index inside one lane: strict '<' keeps the lowest index
-    __device__ __forceinline__ void push(double r, int idx) {
-        if constexpr (K == 1) {
-            if (r < v[0]) { v[0] = r; j[0] = idx; }
-        } else {
-            if (r < v[0]) { v[1] = v[0]; j[1] = j[0]; v[0] = r; j[0] = idx; }
-            else if (r < v[1]) { v[1] = r; j[1] = idx; }
-        }
-    }
-    // merge with another sorted list (lexicographic on (value, index))
-    __device__ __forceinline__ void merge(const double (&ov)[K], const int (&oj)[K]) {
-        if constexpr (K == 1) {
-            if (lex_lt(ov[0], oj[0], v[0], j[0])) { v[0] = ov[0]; j[0] = oj[0]; }
-        } else {
-            double n0, n1; int m0, m1;
-            if (lex_lt(ov[0], oj[0], v[0], j[0])) {
-                n0 = ov[0]; m0 = oj[0];
-                if (lex_lt(v[0], j[0], ov[1], oj[1])) { n1 = v[0]; m1 = j[0]; }
-                else { n1 = ov[1]; m1 = oj[1]; }
-            } else {
-                n0 = v[0]; m0 = j[0];
-                if (lex_lt(ov[0], oj[0], v[1], j[1])) { n1 = ov[0]; m1 = oj[0]; }
-                else { n1 = v[1]; m1 = j[1]; }
-            }
-            v[0] = n0; j[0] = m0; v[1] = n1; j[1] = m1;
-        }
-    }
-};
 
 template <typename XT, int K>
 __global__ __launch_bounds__(NT, 2) void bmu_kernel(
@@ -367,6 +321,12 @@ int launch_bmu(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx, co
     DBGSOM_REQUIRE(X && xx && W && ww && idx && dist, "null pointer");
     const int64_t nb = (N + BI - 1) / BI;
     DBGSOM_REQUIRE(nb <= 0x7fffffff, "too many samples for one launch");
+    static const bool force_generic = []() {
+        const char *e = getenv("DBGSOM_BMU_PATH");  // "generic" forces the register-staged kernel
+        return e && e[0] == 'g';
+    }();
+    if (!force_generic && bmu_dma_usable(X, x_dtype, d, ldx, W))
+        return launch_bmu_dma(X, x_dtype, N, d, ldx, xx, W, M, ww, k, round_f32, idx, dist, s);
     const size_t xe = dtype_size(x_dtype);
     const int xvec = is_aligned(X, 16) && ((ldx * xe) % 16 == 0);
     const int wvec = is_aligned(W, 16) && ((d * 8) % 16 == 0);
