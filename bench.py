@@ -201,7 +201,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg_name, "samples_per_gpu": n_gpu, "features": d,
                        "prototypes": M, "x_storage": "f32", "sharding": f"rows/{world}"},
-            "roofline": {"bound": "mfma", "kernel": "bmu_kernel<float,1>", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "bmu_dma_kernel<float,1>", "achieved": achieved,
                          "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "kernel_ms": bmu_ms},
