@@ -35,6 +35,12 @@ SIGNATURES = {
                                 _sz, _vp]),
     "dbgsom_smooth_workspace_bytes": (_sz, [_i64, _i64]),
     "dbgsom_smooth": (_ci, [_vp, _i64, _i64, _vp, _dbl, _ci, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dbgsom_filter_planes_bytes": (_sz, [_i64, _i64]),
+    "dbgsom_filter_prepare": (_ci, [_vp, _ci, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "dbgsom_bmu_filtered_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "dbgsom_bmu_filtered": (_ci, [_vp, _ci, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
+                                  _ci, _vp, _vp, _vp, _sz, _vp]),
+    "dbgsom_bmu_filtered_counts": (_ci, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "dbgsom_sum_workspace_bytes": (_sz, []),
     "dbgsom_sum_f64": (_ci, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "dbgsom_topographic_count": (_ci, [_vp, _i64, _vp, _i64, _vp, _vp]),

@@ -173,9 +173,18 @@ class HipBackend(HotPathBackend):
 
     name = "hip"
 
-    def __init__(self, device: Optional[int] = None):
+    # the filtered search pays off once the all-pairs float64 work is large
+    FILTER_MIN_PROTOTYPES = 256
+
+    def __init__(self, device: Optional[int] = None, algorithm: str = "auto"):
+        """algorithm: "exact" = all-pairs float64 MFMA search every epoch; "filtered" / "auto" =
+        int8-MFMA candidate filter + exact float64 on the candidates (identical results) whenever
+        it applies (float32 samples, d % 16 == 0, a previous epoch's winners, M >= 256)."""
         self._lib = _native.load()  # raises when the extension is not built
-        self._init_args = (device,)
+        if algorithm not in ("auto", "exact", "filtered"):
+            raise ValueError("algorithm must be 'auto', 'exact' or 'filtered'")
+        self.algorithm = algorithm
+        self._init_args = (device, algorithm)
         import torch
 
         if not torch.cuda.is_available() or _native.device_count() < 1:
@@ -195,6 +204,10 @@ class HipBackend(HotPathBackend):
         self._hop_key = None
         self._hop_dev = None
         self._ws = {}
+        self._planes = None      # digit planes of the resident samples (filtered search)
+        self._prev_idx = None    # winners of the previous epoch (device)
+        self._order = None       # sample ids bucketed by those winners (device, int32)
+        self.last_filter_counts = None
         # bench hook: a list here collects (name, start, end) HIP events recorded on the stream
         # the kernels are launched on
         self.kernel_events = None
@@ -261,6 +274,7 @@ class HipBackend(HotPathBackend):
         self._x_np_dtype = X.dtype
         self._X = Xd
         self._xx = self._norms(self._X, code, X.shape[0], X.shape[1])
+        self._reset_filter_state()
         return self
 
     def load_device(self, X_dev):
@@ -274,7 +288,46 @@ class HipBackend(HotPathBackend):
         self._X = X_dev
         self._xx = self._norms(X_dev, _x_dtype_code(self._x_np_dtype), X_dev.shape[0],
                                X_dev.shape[1])
+        self._reset_filter_state()
         return self
+
+    def _reset_filter_state(self):
+        self._planes = self._prev_idx = self._order = None
+
+    def _filter_applies(self, M):
+        return (self.algorithm != "exact" and self._prev_idx is not None
+                and self._order is not None and not isinstance(self._x_np_dtype, str)
+                and self._x_np_dtype == np.float32 and self._X.shape[1] % 16 == 0
+                and self.FILTER_MIN_PROTOTYPES <= M <= _native.MAX_PROTOTYPES
+                and self._prev_idx.numel() == self._X.shape[0])
+
+    def _bmu_filtered_dev(self, Wd, wwd, round_f32):
+        torch = self._torch
+        N, d = self._X.shape
+        M = Wd.shape[0]
+        if self._planes is None:  # digit planes of X: once per resident sample set
+            nbytes = self._lib.dbgsom_filter_planes_bytes(N, d)
+            self._planes = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _native.call("dbgsom_filter_prepare", self._p(self._X), _native.F32, N, d, d,
+                         self._p(self._planes), nbytes, self._stream())
+        idx = torch.empty((N, 1), dtype=torch.int64, device=self.device)
+        dist = torch.empty((N, 1), dtype=torch.float64, device=self.device)
+        need = self._lib.dbgsom_bmu_filtered_workspace_bytes(N, d, M)
+        ws = self._buf("filter", need)
+        self._timed_call("bmu", "dbgsom_bmu_filtered", self._p(self._X), _native.F32, N, d, d,
+                         self._p(self._xx), self._p(self._planes), self._p(Wd), M, self._p(wwd),
+                         self._p(self._prev_idx), self._p(self._order), round_f32, self._p(idx),
+                         self._p(dist), self._p(ws), ws.numel(), self._stream())
+        return dist, idx
+
+    def filter_counts(self):
+        """Candidate-list length per 128-sample workgroup of the last filtered search."""
+        N, d = self._X.shape
+        nb = (N + 127) // 128
+        out = np.empty(nb, dtype=np.uint32)
+        _native.call("dbgsom_bmu_filtered_counts", self._p(self._ws["filter"]), N, d,
+                     self._last_filter_M, out.ctypes.data, nb, self._stream())
+        return out
 
     @property
     def n_samples(self):
@@ -359,11 +412,19 @@ class HipBackend(HotPathBackend):
         Wd, rf = self._as_dev_weights(W)
         self._W_dev = Wd
         wwd = self._norms(Wd, _native.F64, Wd.shape[0], Wd.shape[1])
-        dist, idx = self._bmu_dev(self._X, self._xx, self._x_np_dtype, Wd, wwd, 1, rf)
+        if self._filter_applies(Wd.shape[0]):
+            self._last_filter_M = Wd.shape[0]
+            dist, idx = self._bmu_filtered_dev(Wd, wwd, rf)
+        else:
+            dist, idx = self._bmu_dev(self._X, self._xx, self._x_np_dtype, Wd, wwd, 1, rf)
         dist, idx = dist.view(-1), idx.view(-1)
         kw = self._exp_similarity_dev(dist, gamma)
         self._last_idx = idx
         sums = self._accumulate_dev(idx, kw, dist, Wd.shape[0])
+        # the next epoch's filter visits the samples bucketed by this epoch's winners: the
+        # stable counting sort the accumulate step just did (first N int32 of its workspace)
+        self._prev_idx = idx
+        self._order = self._ws["acc"][: 4 * idx.numel()].view(self._torch.int32)
         if want_assignments:
             return sums, idx.cpu().numpy(), dist.cpu().numpy()
         return sums, None, None
@@ -493,4 +554,5 @@ class HipBackend(HotPathBackend):
 
     def release(self):
         self._X = self._xx = self._hop_dev = None
+        self._reset_filter_state()
         self._ws.clear()

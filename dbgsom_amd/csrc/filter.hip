@@ -1,0 +1,625 @@
+// Filtered BMU search: an int8-MFMA sweep decides, with a rigorous error bound, which prototypes
+// can possibly be a sample's best matching unit; only those pairs are then evaluated exactly
+// (float64 chain, same arithmetic as bmu.hip / oracle/bmu_chain.c).  Results are IDENTICAL to the
+// all-pairs float64 search -- the filter only removes pairs that provably cannot win.
+//
+// Replaces the same reference step as bmu.hip: BaseSom._get_winning_neurons (BaseSom.py:446-464).
+//
+// 1. slice_rows_kernel: every row a (samples once per fit, prototypes once per epoch) is scaled by
+//    s = max|a_k| and quantised to Q_k = rint(a_k / s * F), F = 127 * 2^16, then split into three
+//    balanced base-256 digits Q = D0 * 2^16 + D1 * 2^8 + D2, D in [-128, 127], stored as int8
+//    planes.  |a_k - s Q_k / F| <= s / (2F).
+// 2. sweep_i8_kernel: v_mfma_i32_32x32x32_i8 forms the six digit products with a + b <= 2,
+//    accumulated EXACTLY in int32 per level L = a + b; T = P0 2^16 + P1 2^8 + P2 and
+//       r~_ij = (|x_i|^2 + |w_j|^2) - 2 s_i t_j 2^16 T / F^2 ,   |r~_ij - r_ij| <= eps_i
+//    with eps_i from the quantisation and the dropped (a + b >= 3) products (formula at
+//    filter_eps below).  Samples are visited in the order of their PREVIOUS winner (the stable
+//    bucket order dbgsom_accumulate produced), so a 128-sample workgroup shares its candidates;
+//    prototype j is marked for the workgroup when r~_ij <= thr_i = r~_{i,prev(i)} + 2 eps_i for any
+//    of its samples i (every j with r_ij <= r_{i,prev(i)} satisfies this, in particular the winner
+//    and everything tied with it).
+// 3. subset_exact_kernel (bmu_dma-style f64 MFMA on gathered rows): exact arg-min of each sample
+//    over its workgroup's marked prototypes = exact arg-min over all prototypes.
+#include <math.h>
+
+#include "bmu_common.h"
+
+namespace dbgsom {
+
+constexpr double FQ = 8323072.0;  // 127 * 2^16
+constexpr int FKT = 64;           // bytes (= features) per plane row per LDS stage
+constexpr int FNT = 512;          // threads per sweep workgroup (8 wavefronts)
+constexpr int FSTAGES = 3;
+
+inline int64_t filter_dpad(int64_t d) { return (d + FKT - 1) / FKT * FKT; }
+
+// ---- 1. digit planes --------------------------------------------------------------------------
+// planes: int8 [3][rows][dpad]; scale[rows] = s; l1[rows] = sum |a_k|
+template <typename T>
+__global__ __launch_bounds__(256) void slice_rows_kernel(const T *__restrict__ A, int64_t rows,
+                                                         int d, int64_t ld, int dpad,
+                                                         int8_t *__restrict__ planes,
+                                                         double *__restrict__ scale,
+                                                         double *__restrict__ l1) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T *a = A + row * ld;
+    double m = 0.0, s1 = 0.0;
+    for (int k = lane; k < d; k += 64) {
+        const double v = fabs(widen(a[k]));
+        m = fmax(m, v);
+        s1 += v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmax(m, __shfl_xor(m, off, 64));
+        s1 += __shfl_xor(s1, off, 64);
+    }
+    const double s = (m > 0.0) ? m : 1.0;
+    if (lane == 0) { scale[row] = s; l1[row] = s1; }
+    const size_t plane_stride = (size_t)rows * dpad;
+    int8_t *p0 = planes + (size_t)row * dpad;
+    for (int k = lane; k < dpad; k += 64) {
+        int q = 0;
+        if (k < d) q = (int)rint(widen(a[k]) / s * FQ);
+        const int d2 = ((q + 128) & 255) - 128;
+        const int q1 = (q - d2) >> 8;
+        const int d1 = ((q1 + 128) & 255) - 128;
+        const int d0 = (q1 - d1) >> 8;
+        p0[k] = (int8_t)d0;
+        p0[plane_stride + k] = (int8_t)d1;
+        p0[2 * plane_stride + k] = (int8_t)d2;
+    }
+}
+
+// per-prototype tables of the sweep, padded with zeros to Mpad (a multiple of 128) entries:
+// ctab_j = 2 t_j 2^16 / F^2 (so r~ = (xx+yy) - s_i ctab_j T), yypad_j = |w_j|^2;
+// summary[0] = max_j l1_j, summary[1] = max_j t_j, summary[2] = max_j |w_j|^2
+__global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict__ tw,
+                                                       const double *__restrict__ l1w,
+                                                       const double *__restrict__ ww, int M,
+                                                       int Mpad, double *__restrict__ ctab,
+                                                       double *__restrict__ yypad,
+                                                       double *__restrict__ summary) {
+    __shared__ double r0[1024], r1[1024], r2[1024];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int j = t; j < Mpad; j += 1024) {
+        if (j >= M) { ctab[j] = 0.0; yypad[j] = 0.0; continue; }
+        ctab[j] = 2.0 * tw[j] * 65536.0 / (FQ * FQ);
+        yypad[j] = ww[j];
+        a = fmax(a, l1w[j]); b = fmax(b, tw[j]); c = fmax(c, ww[j]);
+    }
+    r0[t] = a; r1[t] = b; r2[t] = c;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (t < w) { r0[t] = fmax(r0[t], r0[t + w]); r1[t] = fmax(r1[t], r1[t + w]); r2[t] = fmax(r2[t], r2[t + w]); }
+        __syncthreads();
+    }
+    if (t == 0) { summary[0] = r0[0]; summary[1] = r1[0]; summary[2] = r2[0]; }
+}
+
+// error bound of r~ for sample i against ANY prototype of this epoch:
+//   |x.w - x^.w^| <= (s |w|_1 + t |x|_1) / (2F) + d s t / (4 F^2)          (quantisation)
+//   dropped digit products (a+b >= 3): <= d * 128*128*(2*256 + 1) * s t / F^2
+//   eps = 2 * (sum) + floating-point slack of forming r~
+__device__ __forceinline__ double filter_eps(double s, double l1x, double xx, double l1w_max,
+                                             double t_max, double yy_max, int d) {
+    const double quant = (s * l1w_max + t_max * l1x) / (2.0 * FQ) + (double)d * s * t_max / (4.0 * FQ * FQ);
+    const double dropped = (double)d * (16384.0 * 513.0) * s * t_max / (FQ * FQ);
+    return 2.0 * (quant + dropped) * (1.0 + 1e-9) + 1e-13 * (xx + yy_max);
+}
+
+// ---- 2. the int8 sweep -------------------------------------------------------------------------
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+__device__ __forceinline__ void fdma16(const void *src, void *lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_dst, 16, 0, 0);
+}
+
+constexpr int SW_PLANE = 128 * FKT;                 // 8 KB: one plane of one operand per stage
+constexpr int SW_STAGE = 6 * SW_PLANE;              // X planes 0..2, W planes 0..2
+constexpr int SW_TAB = 128 * 8;                     // one table (128 doubles)
+constexpr int SW_OFF_TAB = FSTAGES * SW_STAGE;      // 3 x (yy | ctab)
+constexpr int SW_OFF_THR = SW_OFF_TAB + 3 * 2 * SW_TAB;
+constexpr int SW_OFF_PREV = SW_OFF_THR + 128 * 8;
+constexpr int SW_OFF_MASK = SW_OFF_PREV + 128 * 4;
+constexpr int SW_MAX_M = 16000;
+constexpr int SW_SMEM = SW_OFF_MASK + (SW_MAX_M + 31) / 32 * 4 + 64;
+
+__global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
+    const int8_t *__restrict__ xplanes, const double *__restrict__ sx,
+    const double *__restrict__ l1x, const double *__restrict__ xx, int64_t N, int d, int dpad,
+    const int8_t *__restrict__ wplanes, const double *__restrict__ ww,
+    const double *__restrict__ ctab, const double *__restrict__ summary, int M,
+    const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
+    uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount) {
+    __shared__ __attribute__((aligned(16))) char smem[SW_SMEM];
+    double *thr_s = reinterpret_cast<double *>(smem + SW_OFF_THR);
+    int *prev_s = reinterpret_cast<int *>(smem + SW_OFF_PREV);
+    uint32_t *mask = reinterpret_cast<uint32_t *>(smem + SW_OFF_MASK);
+    int *misc = reinterpret_cast<int *>(smem + SW_OFF_MASK + (SW_MAX_M + 31) / 32 * 4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 2, wj = wave & 3;  // 2 (samples) x 4 (prototypes) wavefronts, 64 x 32 each
+    const int lc = lane & 31, lh = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * 128;  // first sorted position of this workgroup
+    const int nwords = (M + 31) / 32;
+
+    for (int w = tid; w < nwords; w += FNT) mask[w] = 0u;
+    if (tid < 128) {
+        const int64_t p = p0 + tid;
+        int pj = -1;
+        if (p < N) pj = (int)prev[order[p]];
+        prev_s[tid] = (pj >= 0 && pj < M) ? pj : -1;
+        thr_s[tid] = (p < N) ? INFINITY : -INFINITY;  // no bound yet / padding never marks
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int lo = 0x7fffffff, hi = -1;
+        for (int u = 0; u < 128; ++u) {
+            const int pj = prev_s[u];
+            if (pj >= 0) { lo = min(lo, pj); hi = max(hi, pj); }
+        }
+        misc[0] = (hi >= 0) ? lo : 0;
+        misc[1] = hi;
+    }
+    __syncthreads();
+    const int jlo = misc[0], jhi = misc[1];
+
+    // per-lane sample constants (2 samples: one per 32-column tile)
+    double s_i[2], xx_i[2], eps2_i[2], thr_i[2];
+    int prev_i[2];
+    const double l1w_max = summary[0], t_max = summary[1], yy_max = summary[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int il = wi * 64 + it * 32 + lc;
+        const int64_t p = p0 + il;
+        const int64_t i = (p < N) ? order[p] : order[N - 1];
+        s_i[it] = sx[i];
+        xx_i[it] = xx[i];
+        eps2_i[it] = 2.0 * filter_eps(s_i[it], l1x[i], xx_i[it], l1w_max, t_max, yy_max, d);
+        prev_i[it] = prev_s[il];
+        thr_i[it] = thr_s[il];
+    }
+
+    // ---- DMA sources: wave w loads, per plane, X rows 16w..16w+15 and W rows 16w..16w+15 -------
+    const int dr = 16 * wave + (lane >> 2), dcp = lane & 3;
+    const int dc = dcp ^ ((dr >> 2) & 3);  // source chunk for the linear LDS chunk (swizzle)
+    const int64_t xpos = (p0 + dr < N) ? (p0 + dr) : (N - 1);
+    const size_t xplane_stride = (size_t)N * dpad, wplane_stride = (size_t)M * dpad;
+    const int8_t *xsrc = xplanes + (size_t)order[xpos] * dpad + dc * 16;
+    const int nkt = dpad / FKT;
+    const int nchunk = (M + 127) / 128;
+    const int ntile = nkt * nchunk;
+    const int c0 = jlo / 128;  // the sweep starts at the chunk holding the previous winners
+
+    auto chunk_of = [&](int t) { int c = c0 + t / nkt; return c >= nchunk ? c - nchunk : c; };
+    auto issue = [&](int t) {
+        const int c_t = chunk_of(t), k0 = (t % nkt) * FKT, jc_t = c_t * 128;
+        char *stage = smem + (t % FSTAGES) * SW_STAGE;
+        int jw = jc_t + dr;
+        jw = jw < M ? jw : M - 1;
+        const int8_t *wsrc = wplanes + (size_t)jw * dpad + dc * 16 + k0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            fdma16(xsrc + p * xplane_stride + k0, stage + p * SW_PLANE + 1024 * wave);
+            fdma16(wsrc + p * wplane_stride, stage + (3 + p) * SW_PLANE + 1024 * wave);
+        }
+        if (t % nkt == 0) {  // this chunk's tables: even waves |w|^2, odd waves ctab (identical copies)
+            const int j2 = jc_t + 2 * lane;  // both tables are padded to a multiple of 128 entries
+            char *tab = smem + SW_OFF_TAB + ((t / nkt) % 3) * 2 * SW_TAB;
+            if (wave & 1) fdma16(ctab + j2, tab + SW_TAB);
+            else fdma16(ww + j2, tab);
+        }
+    };
+
+    // fragment read offsets inside a stage
+    int xoff[2], woff;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = wi * 64 + it * 32 + lc;
+        xoff[it] = r * FKT + ((lh ^ ((r >> 2) & 3)) * 16);
+    }
+    {
+        const int r = wj * 32 + lc;
+        woff = 3 * SW_PLANE + r * FKT + ((lh ^ ((r >> 2) & 3)) * 16);
+    }
+    // chunk (2 ks + lh) ^ swz = (2 ks) ^ (lh ^ swz): k-step 1 flips bit 1 of the chunk -> byte 32
+    v16i_t acc[2][3];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int L = 0; L < 3; ++L)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[it][L][r] = 0;
+
+    issue(0);
+    if (ntile > 1) issue(1);
+
+    for (int t = 0; t < ntile; ++t) {
+        if (t + 1 < ntile) {
+            if ((t + 1) % nkt == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntile) issue(t + 2);
+
+        const char *stage = smem + (t % FSTAGES) * SW_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v4i_t xf[2][3], wf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                wf[p] = *reinterpret_cast<const v4i_t *>(stage + p * SW_PLANE + (woff ^ (ks * 32)));
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+                    xf[it][p] = *reinterpret_cast<const v4i_t *>(stage + p * SW_PLANE + (xoff[it] ^ (ks * 32)));
+            }
+            // six digit products, level = plane(x) + plane(w); prototypes = rows (A), samples = cols (B)
+#define DBGSOM_I8(it, px, pw, L) \
+    acc[it][L] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[pw], xf[it][px], acc[it][L], 0, 0, 0)
+            DBGSOM_I8(0, 0, 0, 0); DBGSOM_I8(1, 0, 0, 0);
+            DBGSOM_I8(0, 0, 1, 1); DBGSOM_I8(1, 0, 1, 1);
+            DBGSOM_I8(0, 0, 2, 2); DBGSOM_I8(1, 0, 2, 2);
+            DBGSOM_I8(0, 1, 0, 1); DBGSOM_I8(1, 1, 0, 1);
+            DBGSOM_I8(0, 1, 1, 2); DBGSOM_I8(1, 1, 1, 2);
+            DBGSOM_I8(0, 2, 0, 2); DBGSOM_I8(1, 2, 0, 2);
+#undef DBGSOM_I8
+        }
+
+        if (t % nkt == nkt - 1) {
+            const int c_t = chunk_of(t), jc = c_t * 128;
+            const double *ytab = reinterpret_cast<const double *>(smem + SW_OFF_TAB + ((t / nkt) % 3) * 2 * SW_TAB);
+            const double *ctb = ytab + 128;
+            const bool has_prev = (jc <= jhi) && (jc + 127 >= jlo);
+            // r~ of the lane's 2 x 16 pairs
+            double rv[2][16];
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jl = wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const double T = ((double)acc[it][0][r] * 256.0 + (double)acc[it][1][r]) * 256.0 +
+                                     (double)acc[it][2][r];
+                    rv[it][r] = (xx_i[it] + ytab[jl]) - s_i[it] * (ctb[jl] * T);
+                }
+            if (has_prev) {  // bound from the previous winner: thr_i = r~(i, prev_i) + 2 eps_i
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = jc + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (j == prev_i[it]) thr_s[wi * 64 + it * 32 + lc] = rv[it][r] + eps2_i[it];
+                    }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 2; ++it) thr_i[it] = thr_s[wi * 64 + it * 32 + lc];
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = jc + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (j < M && rv[it][r] <= thr_i[it]) atomicOr(&mask[j >> 5], 1u << (j & 31));
+                }
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int L = 0; L < 3; ++L)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[it][L][r] = 0;
+        }
+    }
+
+    // ---- compact the marked prototypes, ascending ------------------------------------------------
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t base = 0;
+        uint16_t *out = ulist + (size_t)blockIdx.x * ulist_stride;
+        for (int w0 = 0; w0 < nwords; w0 += 64) {
+            const int w = w0 + lane;
+            uint32_t bits = (w < nwords) ? mask[w] : 0u;
+            const uint32_t cnt = __popc(bits);
+            uint32_t pre = cnt;  // inclusive scan over the wavefront
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(pre, off, 64);
+                if (lane >= off) pre += v;
+            }
+            uint32_t pos = base + pre - cnt;
+            while (bits) {
+                const int b = __ffs(bits) - 1;
+                bits &= bits - 1;
+                out[pos++] = (uint16_t)(w * 32 + b);
+            }
+            base += __shfl(pre, 63, 64);
+        }
+        if (lane == 0) ucount[blockIdx.x] = base;
+    }
+}
+
+// ---- 3. exact arg-min over the marked prototypes (float64 MFMA on gathered rows) -----------------
+constexpr int SJ = 32;   // prototypes per step
+constexpr int S_XT = 128 * KT * 4, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 KB + 4 KB
+
+__global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
+    const float *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
+    const double *__restrict__ W, int M, const double *__restrict__ ww,
+    const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
+    const uint32_t *__restrict__ ucount, int round_f32, int64_t *__restrict__ idx_out,
+    double *__restrict__ dist_out) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * S_STAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 4 waves x 32 samples
+    const int lr = lane & 15, lq = lane >> 4;
+    const int64_t p0 = (int64_t)blockIdx.x * 128;
+    const int cnt = (int)ucount[blockIdx.x];
+    const uint16_t *list = ulist + (size_t)blockIdx.x * ulist_stride;
+
+    double xi[2];
+    int64_t isamp[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int64_t p = p0 + wave * 32 + it * 16 + lr;
+        isamp[it] = (p < N) ? order[p] : -1;
+        xi[it] = (p < N) ? xx[isamp[it]] : 0.0;
+    }
+    Best<1> best[2];
+    best[0].init();
+    best[1].init();
+
+    // DMA sources. X tile: 128 rows x 64 B (f32), 8 instructions, wave w issues q = 2w, 2w+1
+    const float *xsrc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int L = 64 * (2 * wave + u) + lane;
+        const int r = L >> 2, cp = L & 3;
+        const int c = cp ^ ((r >> 1) & 3);
+        int64_t p = p0 + r;
+        p = p < N ? p : N - 1;
+        xsrc[u] = X + (int64_t)order[p] * ldx + c * 4;
+    }
+    // W tile: 32 rows x 128 B, 4 instructions, wave w issues q = w: rows 8w..8w+7
+    const int wr = 8 * wave + (lane >> 3), wcp = lane & 7;
+    const int wc = (wcp ^ ((wr >> 1) & 7)) * 2;
+
+    const int nkt = d / KT;
+    const int nstep = (cnt + SJ - 1) / SJ;
+    const int ntile = nkt * nstep;
+
+    auto issue = [&](int t) {
+        const int st = t / nkt, k0 = (t - st * nkt) * KT;
+        char *stage = smem + (t % 3) * S_STAGE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) fdma16(xsrc[u] + k0, stage + 1024 * (2 * wave + u));
+        int pos = st * SJ + wr;
+        pos = pos < cnt ? pos : cnt - 1;
+        const int j = (int)list[pos];
+        fdma16(W + (int64_t)j * d + k0 + wc, stage + S_XT + 1024 * wave);
+    };
+
+    int a_off[2], a_swz[2], b_off[2], b_swz[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ra = u * 16 + lr;  // prototype row inside the 32-row step
+        a_off[u] = S_XT + ra * 128 + (lq & 1) * 8;
+        a_swz[u] = (ra >> 1) & 7;
+        const int rb = wave * 32 + u * 16 + lr;
+        b_off[u] = rb * 64 + lq * 4;
+        b_swz[u] = (rb >> 1) & 3;
+    }
+
+    d4_t acc[2][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    if (ntile > 0) issue(0);
+    if (ntile > 1) issue(1);
+    int kt = 0, st = 0;
+    for (int t = 0; t < ntile; ++t) {
+        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntile) issue(t + 2);
+        const char *stage = smem + (t % 3) * S_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KT / 4; ++ks) {
+            double a[2], b[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ca = (2 * ks + (lq >> 1)) ^ a_swz[u];
+                a[u] = *reinterpret_cast<const double *>(stage + a_off[u] + ca * 16);
+                const int cb = ks ^ b_swz[u];
+                b[u] = (double)*reinterpret_cast<const float *>(stage + b_off[u] + cb * 16);
+            }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+                    acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt], b[it], acc[jt][it],
+                                                                       0, 0, 0);
+        }
+        if (kt == nkt - 1) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pos = st * SJ + jt * 16 + 4 * r + lq;
+                    if (pos < cnt) {
+                        const int j = (int)list[pos];
+                        const double y = ww[j];
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            double rv = (xi[it] + (-2.0 * acc[jt][it][r])) + y;
+                            if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
+                            best[it].push(rv, j);  // list ascends -> j ascends per lane
+                        }
+                    }
+                }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
+            kt = 0;
+            ++st;
+        } else {
+            ++kt;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) {
+            double ov[1] = {__shfl_xor(best[it].v[0], m, 64)};
+            int oj[1] = {__shfl_xor(best[it].j[0], m, 64)};
+            best[it].merge(ov, oj);
+        }
+        if (lq == 0 && isamp[it] >= 0) {
+            double dv = sqrt(best[it].v[0]);
+            if (round_f32) dv = (double)(float)dv;
+            idx_out[isamp[it]] = (best[it].j[0] == 0x7fffffff) ? (int64_t)-1 : (int64_t)best[it].j[0];
+            dist_out[isamp[it]] = dv;
+        }
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------
+struct PlaneBuf {
+    int8_t *planes;
+    double *scale, *l1;
+};
+static size_t carve_planes(PlaneBuf *b, char *base, int64_t rows, int64_t d) {
+    const int64_t dpad = filter_dpad(d);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t o0 = take((size_t)3 * rows * dpad), o1 = take((size_t)rows * 8), o2 = take((size_t)rows * 8);
+    if (b) { b->planes = (int8_t *)(base + o0); b->scale = (double *)(base + o1); b->l1 = (double *)(base + o2); }
+    return off;
+}
+
+struct FilterWs {
+    PlaneBuf w;
+    double *ctab, *yypad, *summary;
+    uint16_t *ulist;
+    uint32_t *ucount;
+    int64_t nb, Mpad;
+};
+static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_t M) {
+    const int64_t Mpad = (M + 127) / 128 * 128, nb = (N + 127) / 128;
+    size_t off = carve_planes(f ? &f->w : nullptr, base, M, d);
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t o0 = take((size_t)Mpad * 8), o1 = take((size_t)Mpad * 8), o2 = take(64);
+    const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
+    if (f) {
+        f->ctab = (double *)(base + o0); f->yypad = (double *)(base + o1);
+        f->summary = (double *)(base + o2); f->ulist = (uint16_t *)(base + o3);
+        f->ucount = (uint32_t *)(base + o4); f->nb = nb; f->Mpad = Mpad;
+    }
+    return off;
+}
+
+static int launch_slice(const void *A, int dtype, int64_t rows, int64_t d, int64_t ld,
+                        const PlaneBuf &b, hipStream_t s) {
+    const int dpad = (int)filter_dpad(d);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == DBGSOM_F32)
+        hipLaunchKernelGGL(slice_rows_kernel<float>, grid, block, 0, s, (const float *)A, rows, (int)d, ld, dpad, b.planes, b.scale, b.l1);
+    else if (dtype == DBGSOM_F64)
+        hipLaunchKernelGGL(slice_rows_kernel<double>, grid, block, 0, s, (const double *)A, rows, (int)d, ld, dpad, b.planes, b.scale, b.l1);
+    else
+        hipLaunchKernelGGL(slice_rows_kernel<bf16_t>, grid, block, 0, s, (const bf16_t *)A, rows, (int)d, ld, dpad, b.planes, b.scale, b.l1);
+    return launch_status("slice_rows_kernel");
+}
+
+}  // namespace dbgsom
+
+using namespace dbgsom;
+
+extern "C" {
+
+size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d) {
+    if (rows < 1 || d < 1) return 0;
+    return carve_planes(nullptr, nullptr, rows, d);
+}
+
+int dbgsom_filter_prepare(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                          void *planes_dev, size_t planes_bytes, void *stream) {
+    DBGSOM_REQUIRE(valid_dtype(x_dtype) && N >= 1 && d >= 1 && ldx >= d && N < 0x7fffffff,
+                   "bad samples");
+    DBGSOM_REQUIRE(X_dev && planes_dev && is_aligned(planes_dev, 256), "bad pointer");
+    if (planes_bytes < dbgsom_filter_planes_bytes(N, d)) {
+        set_error("dbgsom_filter_prepare: planes buffer too small");
+        return DBGSOM_ENOMEM;
+    }
+    PlaneBuf b;
+    carve_planes(&b, (char *)planes_dev, N, d);
+    return launch_slice(X_dev, x_dtype, N, d, ldx, b, (hipStream_t)stream);
+}
+
+size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M) {
+    if (N < 1 || d < 1 || M < 1) return 0;
+    return carve_filter(nullptr, nullptr, N, d, M);
+}
+
+int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                        const double *xx_dev, const void *xplanes_dev, const double *W_dev,
+                        int64_t M, const double *ww_dev, const int64_t *prev_idx_dev,
+                        const int32_t *order_dev, int round_f32, int64_t *idx_dev,
+                        double *dist_dev, void *workspace_dev, size_t workspace_bytes,
+                        void *stream) {
+    DBGSOM_REQUIRE(x_dtype == DBGSOM_F32, "the filtered search takes float32 samples");
+    DBGSOM_REQUIRE(N >= 1 && N < 0x7fffffff && d >= 1 && d % KT == 0 && ldx >= d, "bad sample shape (d must be a multiple of 16)");
+    DBGSOM_REQUIRE(M >= 1 && M <= SW_MAX_M, "M outside [1, 16000]");
+    DBGSOM_REQUIRE(X_dev && xx_dev && xplanes_dev && W_dev && ww_dev && prev_idx_dev && order_dev &&
+                       idx_dev && dist_dev && workspace_dev, "null pointer");
+    DBGSOM_REQUIRE(is_aligned(X_dev, 16) && (ldx * 4) % 16 == 0 && is_aligned(W_dev, 16) &&
+                       is_aligned(workspace_dev, 256) && is_aligned(xplanes_dev, 256), "alignment");
+    if (workspace_bytes < dbgsom_bmu_filtered_workspace_bytes(N, d, M)) {
+        set_error("dbgsom_bmu_filtered: workspace too small");
+        return DBGSOM_ENOMEM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    PlaneBuf xb;
+    carve_planes(&xb, (char *)const_cast<void *>(xplanes_dev), N, d);
+    FilterWs f;
+    carve_filter(&f, (char *)workspace_dev, N, d, M);
+    const int dpad = (int)filter_dpad(d);
+    int rc = launch_slice(W_dev, DBGSOM_F64, M, d, d, f.w, s);
+    if (rc != DBGSOM_OK) return rc;
+    hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.w.scale, f.w.l1, ww_dev, (int)M,
+                       (int)f.Mpad, f.ctab, f.yypad, f.summary);
+    hipLaunchKernelGGL(sweep_i8_kernel, dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes, xb.scale,
+                       xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab, f.summary, (int)M,
+                       prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount);
+    hipLaunchKernelGGL(subset_exact_kernel, dim3((unsigned)f.nb), dim3(NT), 0, s,
+                       (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev,
+                       f.ulist, (int)f.Mpad, f.ucount, round_f32, idx_dev, dist_dev);
+    return launch_status("filtered bmu kernels");
+}
+
+/* diagnostics: sizes of the per-workgroup candidate lists of the last dbgsom_bmu_filtered call */
+int dbgsom_bmu_filtered_counts(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
+                               uint32_t *counts_host, int64_t n_counts, void *stream) {
+    DBGSOM_REQUIRE(workspace_dev && counts_host, "null pointer");
+    FilterWs f;
+    carve_filter(&f, (char *)const_cast<void *>(workspace_dev), N, d, M);
+    DBGSOM_REQUIRE(n_counts == f.nb, "n_counts must be ceil(N / 128)");
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(counts_host, f.ucount, (size_t)f.nb * 4, hipMemcpyDeviceToHost,
+                                    (hipStream_t)stream));
+    DBGSOM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return DBGSOM_OK;
+}
+
+}  // extern "C"

@@ -109,6 +109,31 @@ int dbgsom_smooth(const double *sums_dev, int64_t M, int64_t d, const float *hop
                   double *change_total_dev, void *workspace_dev, size_t workspace_bytes,
                   void *stream);
 
+/* ---- filtered BMU search: identical results, most float64 work removed -------------------------
+ * An int8-MFMA sweep over 3 x 8-bit digit planes of X and W bounds every r_ij with a rigorous
+ * per-sample error eps_i; prototype j stays a candidate of a 128-sample workgroup when
+ * r~_ij <= r~_{i,prev(i)} + 2 eps_i for one of its samples (prev = winner of the previous epoch);
+ * the exact float64 search (same arithmetic as dbgsom_bmu) then runs on the candidates only.
+ * Same reference step as dbgsom_bmu (BaseSom.py:446-464), k = 1, float32 samples, d % 16 == 0.
+ *   xplanes_dev : filled once per fit by dbgsom_filter_prepare (digit planes + row scales of X)
+ *   prev_idx_dev: N winners of the previous epoch (any valid indices < M keep the result exact;
+ *                 good ones keep the candidate sets small)
+ *   order_dev   : the N sample ids bucketed by prev_idx -- the first N int32 of the workspace of
+ *                 the previous dbgsom_accumulate call */
+size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d);
+int dbgsom_filter_prepare(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                          void *planes_dev, size_t planes_bytes, void *stream);
+size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M);
+int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                        const double *xx_dev, const void *xplanes_dev, const double *W_dev,
+                        int64_t M, const double *ww_dev, const int64_t *prev_idx_dev,
+                        const int32_t *order_dev, int round_f32, int64_t *idx_dev,
+                        double *dist_dev, void *workspace_dev, size_t workspace_bytes,
+                        void *stream);
+/* diagnostics: candidate-list length of every 128-sample workgroup of the last filtered call */
+int dbgsom_bmu_filtered_counts(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
+                               uint32_t *counts_host, int64_t n_counts, void *stream);
+
 /* ---- post-fit consumers of the BMU step as device reductions (N-sized arrays stay in HBM) ---- */
 
 /* out[0] = sum of v[0..n) with a fixed reduction tree (bitwise reproducible).  Mean BMU distance =

@@ -345,3 +345,67 @@ def test_bf16_storage_matches_oracle_on_rounded_samples(hip, o, N, d, M):
     d2, i2 = hip.bmu(W, 2)
     rd, ri = o.bmu_chain(Xr, W, 2)
     assert np.array_equal(i2, ri) and np.array_equal(d2, rd)
+
+
+@pytest.mark.parametrize("N,d,rows,cols", [(20000, 784, 16, 16), (5000, 64, 18, 19),
+                                            (12345, 128, 17, 17)])
+def test_filtered_search_is_identical_to_exact(o, N, d, rows, cols):
+    """The int8-MFMA filter + exact re-evaluation must reproduce the all-pairs float64 search bit
+    for bit, over several epochs of a moving map (the filter uses the previous epoch's winners)."""
+    from dbgsom_amd.backend import HipBackend
+
+    M = rows * cols
+    X, _ = gi.blobs_f32(N, d, 4242 + d)
+    W = X[np.random.default_rng(1).choice(N, M, replace=False)].astype(np.float64)
+    hop = gi.lattice_hops(rows, cols)
+    gamma = float(1.0 / np.var(X, axis=0).sum())
+    exact = HipBackend(algorithm="exact").load(X)
+    filt = HipBackend(algorithm="filtered").load(X)
+    sigma = 0.2 * np.sqrt(M)
+    We, Wf = W, W
+    for e in range(5):
+        re_ = exact.epoch(We, hop, sigma, gamma, "compact", True)
+        rf = filt.epoch(Wf, hop, sigma, gamma, "compact", True)
+        assert np.array_equal(re_.winners, rf.winners), f"epoch {e}"
+        assert np.array_equal(re_.distances, rf.distances), f"epoch {e}"
+        assert np.array_equal(re_.new_weights, rf.new_weights), f"epoch {e}"
+        We, Wf = re_.new_weights, rf.new_weights
+        if e >= 1:
+            counts = filt.filter_counts()
+            assert counts.min() >= 1 and counts.max() <= M
+        sigma *= 0.6
+    # epoch 0 ran the exact kernel (no previous winners); the others must have used the filter
+    assert filt._planes is not None
+    # oracle spot check of the last filtered epoch
+    pick = np.random.default_rng(0).choice(N, 1500, replace=False)
+    W_last_in = We if False else None  # (weights fed to the last epoch are not kept; check below)
+    d1, i1 = filt.bmu(rf.new_weights, 1)
+    rd, ri = o.bmu_chain(X[pick], rf.new_weights, 1)
+    assert np.array_equal(i1[pick], ri) and np.array_equal(d1[pick], rd)
+
+
+def test_filtered_search_with_ties_and_bad_previous_winners(o):
+    """Duplicated prototypes (exact ties -> lowest index) and deliberately wrong previous winners:
+    the result must not depend on the quality of the hint."""
+    from dbgsom_amd.backend import HipBackend
+    import torch
+
+    rng = np.random.default_rng(5)
+    N, d, M = 6000, 32, 300
+    X = rng.integers(-3, 4, size=(N, d)).astype(np.float32)
+    base = rng.integers(-3, 4, size=(M // 3, d)).astype(np.float64)
+    W = np.concatenate([base, base, base])  # every prototype appears 3 times
+    be = HipBackend(algorithm="filtered").load(X)
+    hop = gi.lattice_hops(15, 20)
+    r0 = be.epoch(W, hop, 2.0, 0.01, "compact", True)      # exact kernel, sets the hint
+    r1 = be.epoch(W, hop, 2.0, 0.01, "compact", True)      # filtered, same W -> same answer
+    assert np.array_equal(r0.winners, r1.winners) and np.array_equal(r0.distances, r1.distances)
+    assert (r1.winners < M // 3).all()
+    rd, ri = o.bmu_chain(X, W, 1)
+    assert np.array_equal(r1.winners, ri) and np.array_equal(r1.distances, rd)
+    # poison the hint: random previous winners (the bucket order must match them)
+    bad = torch.from_numpy(rng.integers(0, M, size=N)).to(be.device)
+    order = torch.argsort(bad, stable=True).to(torch.int32)
+    be._prev_idx, be._order = bad, order
+    r2 = be.epoch(W, hop, 2.0, 0.01, "compact", True)
+    assert np.array_equal(r2.winners, ri) and np.array_equal(r2.distances, rd)
