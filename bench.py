@@ -100,6 +100,50 @@ def cpu_baseline(workload, Xs, W, hop, sigma, gamma, n_full):
     }
 
 
+def fine_phase_regime(torch, td, args, X, ctl, M, d, hop, gamma, local, world, sync):
+    """Secondary measurement: epochs of the FINE training phase (BaseSom.py:395-396, 899-900:
+    constant sigma_end = max(0.7, 0.05 sqrt(M)), no growth) on a map that a decaying-sigma
+    warm-up has organised, prototypes evolving from step to step as in training.  Timed for the
+    exact search and for the filtered search (int8-MFMA candidate filter seeded with the previous
+    epoch's winners + exact float64 on the candidates; identical results)."""
+    from dbgsom_amd.backend import HipBackend
+
+    sig0, sig1 = 0.2 * np.sqrt(M), max(0.7, 0.05 * np.sqrt(M))
+    schedule = [sig1 + (sig0 - sig1) * np.exp(-0.35 * e) for e in range(14)]
+    out = {"sigma": sig1, "warmup_epochs": len(schedule)}
+    for algo in ("exact", "filtered"):
+        be = HipBackend(local, algorithm=algo)
+        be.load_device(X)
+        W = ctl[:M * d].reshape(M, d).clone()
+        for s_ in schedule:  # untimed: organise the map
+            W = be.epoch(W, hop, s_, gamma, "compact", False, keep_on_device=True).new_weights_dev
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = be.epoch(W, hop, sig1, gamma, "compact", False, keep_on_device=True)
+            W = res.new_weights_dev
+        sync()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=X.device)
+        if world > 1:
+            td.all_reduce(el, op=td.ReduceOp.MAX)
+        el = float(el.item())
+        out[algo] = {"ms_per_step": el / args.steps * 1e3,
+                     "value": X.shape[0] * world * args.steps / el,
+                     "dead_neurons": int((res.activations == 0).sum())}
+        if algo == "filtered":
+            c = be.filter_counts()
+            out[algo]["candidates_per_workgroup"] = {"mean": float(c.mean()),
+                                                     "p90": float(np.percentile(c, 90)),
+                                                     "max": int(c.max())}
+            out[algo]["checksum_equal_to_exact"] = bool(
+                abs(float(W.sum().item()) - out["_wsum"]) == 0.0)
+        else:
+            out["_wsum"] = float(W.sum().item())
+        be.release()
+    out.pop("_wsum", None)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +151,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--samples-per-gpu", type=int, default=None, help="override N per GPU")
+    ap.add_argument("--fine-phase", type=int, default=1,
+                    help="also time a trained map in the fine phase (sigma_end, evolving W) with "
+                         "the exact and the filtered search (0 disables)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="upper bound of rows timed by the CPU baseline (0 disables it); the "
                          "actual sample is sized for ~15 s of CPU work")
@@ -136,7 +183,9 @@ def main():
     if args.samples_per_gpu:
         n_gpu = args.samples_per_gpu
     M = rows * cols
-    hip = HipBackend(local)
+    # headline: the exact all-pairs float64 search -- its time does not depend on the data or on
+    # anything a previous step left behind
+    hip = HipBackend(local, algorithm="exact")
     X = make_shard(torch, n_gpu, d, seed + rank, device)
     hip.load_device(X)
 
@@ -177,6 +226,9 @@ def main():
     elapsed = float(tmax.item())
 
     ev = hip.kernel_events
+    fine = None
+    if args.fine_phase:
+        fine = fine_phase_regime(torch, td, args, X, ctl, M, d, hop, gamma, local, world, sync)
     bmu_ms = float(np.mean([a.elapsed_time(b) for (k, a, b) in ev if k == "bmu"]))
     acc_ms = float(np.mean([a.elapsed_time(b) for (k, a, b) in ev if k == "accumulate"]))
     smooth_ms = float(np.mean([a.elapsed_time(b) for (k, a, b) in ev if k == "smooth"]))
@@ -208,6 +260,8 @@ def main():
             "phases_ms": {"bmu": bmu_ms, "accumulate": acc_ms, "smooth": smooth_ms,
                           "accumulate_GBps": n_gpu * d * 4 / (acc_ms * 1e-3) / 1e9},
         }
+        if args.fine_phase:
+            out["fine_phase"] = fine
         if args.cpu_sample > 0:
             ns = min(args.cpu_sample, n_gpu)
             Xs = X[:ns].cpu().numpy()

@@ -175,6 +175,11 @@ class HipBackend(HotPathBackend):
 
     # the filtered search pays off once the all-pairs float64 work is large
     FILTER_MIN_PROTOTYPES = 256
+    # "auto": when the candidate lists of a filtered epoch average more than this many
+    # prototypes per 128-sample workgroup (near-duplicate prototypes, e.g. a collapsed map) the
+    # exact all-pairs kernel is cheaper: use it for the next FILTER_BACKOFF epochs, then re-probe
+    FILTER_MAX_MEAN_CANDIDATES = 320
+    FILTER_BACKOFF = 8
 
     def __init__(self, device: Optional[int] = None, algorithm: str = "auto"):
         """algorithm: "exact" = all-pairs float64 MFMA search every epoch; "filtered" / "auto" =
@@ -207,7 +212,9 @@ class HipBackend(HotPathBackend):
         self._planes = None      # digit planes of the resident samples (filtered search)
         self._prev_idx = None    # winners of the previous epoch (device)
         self._order = None       # sample ids bucketed by those winners (device, int32)
-        self.last_filter_counts = None
+        self._filter_backoff = 0
+        self._filtered_this_epoch = False
+        self.filter_log = []     # (epoch kind, mean candidates) of the last epochs, diagnostics
         # bench hook: a list here collects (name, start, end) HIP events recorded on the stream
         # the kernels are launched on
         self.kernel_events = None
@@ -295,6 +302,8 @@ class HipBackend(HotPathBackend):
         self._planes = self._prev_idx = self._order = None
 
     def _filter_applies(self, M):
+        if self.algorithm == "auto" and self._filter_backoff > 0:
+            return False
         return (self.algorithm != "exact" and self._prev_idx is not None
                 and self._order is not None and not isinstance(self._x_np_dtype, str)
                 and self._x_np_dtype == np.float32 and self._X.shape[1] % 16 == 0
@@ -414,8 +423,12 @@ class HipBackend(HotPathBackend):
         wwd = self._norms(Wd, _native.F64, Wd.shape[0], Wd.shape[1])
         if self._filter_applies(Wd.shape[0]):
             self._last_filter_M = Wd.shape[0]
+            self._filtered_this_epoch = True
             dist, idx = self._bmu_filtered_dev(Wd, wwd, rf)
         else:
+            self._filtered_this_epoch = False
+            if self._filter_backoff > 0:
+                self._filter_backoff -= 1
             dist, idx = self._bmu_dev(self._X, self._xx, self._x_np_dtype, Wd, wwd, 1, rf)
         dist, idx = dist.view(-1), idx.view(-1)
         kw = self._exp_similarity_dev(dist, gamma)
@@ -460,7 +473,25 @@ class HipBackend(HotPathBackend):
         if n_classes > 0:
             res.class_hist = self._class_hist_dev(self._last_idx, n_classes, Wn.shape[0])
         self._last_idx = None
+        self._update_filter_policy()
         return res
+
+    def _update_filter_policy(self):
+        """After the epoch has completed (the stream is already synchronised): look at how long
+        the candidate lists were and decide what the next epochs use."""
+        if not self._filtered_this_epoch:
+            if self.algorithm != "exact":
+                self.filter_log.append(("exact", None))
+            return
+        mean = float(self.filter_counts().mean())
+        self.filter_log.append(("filtered", mean))
+        del self.filter_log[:-64]
+        if self.algorithm == "auto":
+            if mean > self.FILTER_MAX_MEAN_CANDIDATES:  # exponential back-off, capped
+                self._filter_fail = min(getattr(self, "_filter_fail", 0) + 1, 6)
+                self._filter_backoff = self.FILTER_BACKOFF << (self._filter_fail - 1)
+            else:
+                self._filter_fail = 0
 
     # -- f-2 / f-3: reductions that keep the N-sized arrays in HBM -----------------------------
     def _bmu_resident_dev(self, W, k):
