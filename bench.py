@@ -105,22 +105,25 @@ def fine_phase_regime(torch, td, args, X, ctl, M, d, hop, gamma, local, world, s
     constant sigma_end = max(0.7, 0.05 sqrt(M)), no growth) on a map that a decaying-sigma
     warm-up has organised, prototypes evolving from step to step as in training.  Timed for the
     exact search and for the filtered search (int8-MFMA candidate filter seeded with the previous
-    epoch's winners + exact float64 on the candidates; identical results)."""
+    epoch's winners + exact float64 on the candidates; identical results).  Uses
+    centres_layout="aligned": with the reference's compacted centre rows (quirk Q1) a 32x32 map
+    with dead neurons scrambles itself into near-duplicate prototypes (the headline regime above
+    does exactly that), which is not what a trained map looks like."""
     from dbgsom_amd.backend import HipBackend
 
     sig0, sig1 = 0.2 * np.sqrt(M), max(0.7, 0.05 * np.sqrt(M))
     schedule = [sig1 + (sig0 - sig1) * np.exp(-0.35 * e) for e in range(14)]
-    out = {"sigma": sig1, "warmup_epochs": len(schedule)}
+    out = {"sigma": sig1, "warmup_epochs": len(schedule), "centres_layout": "aligned"}
     for algo in ("exact", "filtered"):
         be = HipBackend(local, algorithm=algo)
         be.load_device(X)
         W = ctl[:M * d].reshape(M, d).clone()
         for s_ in schedule:  # untimed: organise the map
-            W = be.epoch(W, hop, s_, gamma, "compact", False, keep_on_device=True).new_weights_dev
+            W = be.epoch(W, hop, s_, gamma, "aligned", False, keep_on_device=True).new_weights_dev
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            res = be.epoch(W, hop, sig1, gamma, "compact", False, keep_on_device=True)
+            res = be.epoch(W, hop, sig1, gamma, "aligned", False, keep_on_device=True)
             W = res.new_weights_dev
         sync()
         el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=X.device)
