@@ -398,6 +398,9 @@ class HipBackend(HotPathBackend):
         if M > _native.MAX_PROTOTYPES:
             raise ValueError(f"M={M} exceeds DBGSOM_MAX_PROTOTYPES={_native.MAX_PROTOTYPES}")
         sums = torch.empty(M * (d + 3), dtype=torch.float64, device=self.device)
+        # the workspace's bucket order is about to be rewritten: the (winners, order) pair the
+        # filtered search relies on is only re-established by _local_sums
+        self._prev_idx = self._order = None
         need = self._lib.dbgsom_accumulate_workspace_bytes(N, d, M)
         ws = self._buf("acc", need)
         status = self._buf("status", 256)

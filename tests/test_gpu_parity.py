@@ -409,3 +409,26 @@ def test_filtered_search_with_ties_and_bad_previous_winners(o):
     be._prev_idx, be._order = bad, order
     r2 = be.epoch(W, hop, 2.0, 0.01, "compact", True)
     assert np.array_equal(r2.winners, ri) and np.array_equal(r2.distances, rd)
+
+
+def test_auto_policy_backs_off_on_near_duplicate_prototypes(o):
+    """A map of near-duplicate prototypes makes every prototype a candidate: "auto" must notice
+    and return to the exact kernel (results identical either way)."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(8)
+    N, d, M = 8000, 64, 400
+    X = rng.normal(size=(N, d)).astype(np.float32)
+    W = np.tile(rng.normal(size=(1, d)), (M, 1)) + 1e-9 * rng.normal(size=(M, d))
+    hop = gi.lattice_hops(20, 20)
+    be = HipBackend(algorithm="auto").load(X)
+    ex = HipBackend(algorithm="exact").load(X)
+    kinds = []
+    for e in range(5):
+        r = be.epoch(W, hop, 1.0, 1e-3, "aligned", True)
+        q = ex.epoch(W, hop, 1.0, 1e-3, "aligned", True)
+        assert np.array_equal(r.winners, q.winners) and np.array_equal(r.distances, q.distances)
+        kinds.append(be.filter_log[-1][0])
+    assert kinds[0] == "exact" and kinds[1] == "filtered"   # probe once ...
+    assert kinds[2:] == ["exact"] * 3                        # ... then back off
+    assert be.filter_log[1][1] > HipBackend.FILTER_MAX_MEAN_CANDIDATES
