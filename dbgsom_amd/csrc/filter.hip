@@ -99,15 +99,23 @@ __global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict_
     if (t == 0) { summary[0] = r0[0]; summary[1] = r1[0]; summary[2] = r2[0]; }
 }
 
-// error bound of r~ for sample i against ANY prototype of this epoch:
-//   |x.w - x^.w^| <= (s |w|_1 + t |x|_1) / (2F) + d s t / (4 F^2)          (quantisation)
-//   dropped digit products (a+b >= 3): <= d * 128*128*(2*256 + 1) * s t / F^2
-//   eps = 2 * (sum) + floating-point slack of forming r~
+// Error bound of r~ for sample i against ANY prototype of this epoch, measured against the value
+// the exact kernel computes (r_chain):
+//   quantisation   |a_k - s Q_k / F| <= (s / F)(1/2 + 3 u F)  (the division and the product by F
+//                  are rounded before rint)  ->  |x.w - x^.w^| <= [(s |w|_1 + t |x|_1) / (2F)
+//                  + d s t / (4 F^2)] (1 + 1e-7)
+//   dropped digit products (a + b >= 3): <= d * 128 * 128 * (2 * 256 + 1) * s t / F^2
+//   float64 rounding of forming r~ and of the exact kernel's own fma chain (d u |x||w| each):
+//                  <= 4 (d + 16) 2^-53 (|x|^2 + max |w|^2)
+//   eps = 2 (quantisation + dropped) + rounding.
+// A prototype j with r_chain(i, j) <= r_chain(i, prev) has r~_j <= r~_prev + 2 eps: the test the
+// sweep applies.
 __device__ __forceinline__ double filter_eps(double s, double l1x, double xx, double l1w_max,
                                              double t_max, double yy_max, int d) {
     const double quant = (s * l1w_max + t_max * l1x) / (2.0 * FQ) + (double)d * s * t_max / (4.0 * FQ * FQ);
     const double dropped = (double)d * (16384.0 * 513.0) * s * t_max / (FQ * FQ);
-    return 2.0 * (quant + dropped) * (1.0 + 1e-9) + 1e-13 * (xx + yy_max);
+    const double rounding = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xx + yy_max);
+    return 2.0 * (quant + dropped) * (1.0 + 1e-7) + rounding;
 }
 
 // ---- 2. the int8 sweep -------------------------------------------------------------------------
