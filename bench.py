@@ -127,7 +127,7 @@ def fine_phase_regime(torch, td, args, X, ctl, M, d, hop, gamma, local, world, s
             W = res.new_weights_dev
         sync()
         el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=X.device)
-        if world > 1:
+        if td.is_initialized():
             td.all_reduce(el, op=td.ReduceOp.MAX)
         el = float(el.item())
         out[algo] = {"ms_per_step": el / args.steps * 1e3,
@@ -178,8 +178,12 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # under torch.distributed.run the group is always created (also for one rank: that run is
+    # the single-GPU rehearsal of the RCCL path)
+    grouped = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     n_gpu, d, rows, cols, seed, cfg_name = WORKLOADS[args.workload]
@@ -199,7 +203,7 @@ def main():
         sel = torch.randperm(n_gpu, device=device, generator=g)[:M]
         ctl[:M * d] = X[sel].double().reshape(-1)
         ctl[M * d] = 1.0 / X.double().var(dim=0, unbiased=False).sum()
-    if world > 1:
+    if grouped:
         td.broadcast(ctl, 0)
     W = ctl[:M * d].reshape(M, d).cpu().numpy()
     gamma = float(ctl[M * d].item())
@@ -207,7 +211,7 @@ def main():
     sigma = 0.2 * np.sqrt(M)  # BaseSom.py:876 at epoch 0
 
     def sync():
-        if world > 1:
+        if grouped:
             td.barrier()
         torch.cuda.synchronize()
 
@@ -224,7 +228,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if grouped:
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
@@ -272,7 +276,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload, Xs, W0, hop, sigma, gamma, n_gpu)
             out["gpu_vs_cpu"] = (n_gpu * args.steps / elapsed) / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         td.barrier()
         td.destroy_process_group()
 

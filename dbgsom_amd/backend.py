@@ -56,6 +56,15 @@ def dist_info():
     return 0, 1
 
 
+def _group_is_up() -> bool:
+    try:
+        import torch.distributed as td
+
+        return td.is_available() and td.is_initialized()
+    except ImportError:  # pragma: no cover
+        return False
+
+
 class HotPathBackend:
     """Epoch template shared by the HIP backend and the test-only oracle backend:
     local per-prototype sums -> (all-reduce across sample shards) -> smoothing."""
@@ -86,7 +95,10 @@ class HotPathBackend:
     # -- shared -------------------------------------------------------------------------------
     def _all_reduce(self, sums):
         rank, world = dist_info()
-        if world > 1:
+        # DBGSOM_FORCE_COLLECTIVE=1: issue the collective even in a 1-rank group (rehearsal of
+        # the RCCL path on a single-GPU box)
+        force = os.environ.get("DBGSOM_FORCE_COLLECTIVE") == "1"
+        if world > 1 or (force and _group_is_up()):
             import torch.distributed as td
 
             td.all_reduce(sums, op=td.ReduceOp.SUM)  # one collective per epoch
