@@ -5,8 +5,15 @@
 
 One "step" = one epoch of the hot path (reference dbgsom/BaseSom.py:403-407: BMU search, sample
 kernel, per-neuron sums, [all-reduce], neighbourhood smoothing, convergence norm, per-neuron
-error) on a frozen rectangular map, the samples already resident in HBM.  Each step feeds the
-previous step's new prototypes back in, as training does.
+error) at the FROZEN map of SURVEY.md 8(d): full rows x cols lattice, prototypes = M rows of the
+samples, sigma = 0.2 sqrt(M), gamma = 1 / sum of variances, samples resident in HBM.  Every step
+starts from the same prototypes and computes everything again.
+
+The headline uses the stateless filtered search (`algorithm="filtered"`: coarse int8-MFMA pre-pass
+-> int8 candidate sweep with a rigorous error bound -> exact float64 search on the candidates;
+results bit-identical to the all-pairs float64 search, nothing carried over between steps).  The
+same JSON line also carries the all-pairs exact search (`exact`) and a training-like secondary
+regime (`fine_phase`).
 
 For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU, RCCL);
 samples are sharded by rows (each rank generates its own shard: weak scaling, per-GPU work
@@ -15,6 +22,7 @@ fixed) and the only collective is the all-reduce of the [S|K|a|E] sums, once per
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -33,6 +41,10 @@ WORKLOADS = {
     "c2": (60_000, 784, 22, 23, 1002, "Fashion-MNIST stand-in 60k x 784 fp32, M=506 (22x23)"),
 }
 F64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 cycles (v_mfma_f64_16x16x4_f64)
+I8_MFMA_PEAK_TOPS = 5033.0   # 256 x 4 x 2.4 GHz x 65536 op / 32 cycles (v_mfma_i32_32x32x32_i8, dense)
+# HBM-side bytes of one sweep_i8_kernel<0> launch at C4 from the PMC pass committed under
+# profiles/ (FETCH_SIZE x 2 per the gfx950 correction); not measurable inside this process
+SWEEP_TRAFFIC_C4_BYTES = 2.63e10
 
 
 def lattice_hops(rows, cols):
@@ -100,50 +112,112 @@ def cpu_baseline(workload, Xs, W, hop, sigma, gamma, n_full):
     }
 
 
-def fine_phase_regime(torch, td, args, X, ctl, M, d, hop, gamma, local, world, sync):
+class Harness:
+    def __init__(self, torch, td, args, local, world, grouped):
+        self.torch, self.td, self.args = torch, td, args
+        self.local, self.world, self.grouped = local, world, grouped
+
+    def sync(self):
+        if self.grouped:
+            self.td.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        t = self.torch.tensor([seconds], dtype=self.torch.float64,
+                              device=self.torch.device("cuda", self.local))
+        if self.grouped:
+            self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_epochs(self, be, step_fn, warmup, steps):
+        """W untimed steps, then exactly `steps` timed ones bracketed by barrier + synchronize;
+        returns (max-over-ranks seconds, per-phase mean ms from HIP events on the launch stream)."""
+        be.kernel_events = None
+        for _ in range(warmup):
+            step_fn()
+        be.kernel_events = []
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        self.sync()
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        ev, be.kernel_events = be.kernel_events, None
+        phases = {k: float(np.mean([a.elapsed_time(b) for (kk, a, b) in ev if kk == k]))
+                  for k in ("bmu", "accumulate", "smooth")}
+        return elapsed, phases
+
+
+def frozen_map_regime(h, algorithm, X, W0, hop, sigma, gamma):
+    """every step = one full epoch from the SAME frozen prototypes."""
+    from dbgsom_amd import _native
+    from dbgsom_amd.backend import HipBackend
+
+    be = HipBackend(h.local, algorithm=algorithm)
+    be.load_device(X)
+    stage = None
+    if algorithm != "exact":
+        _native.call("dbgsom_filter_timing", 1)
+    last = {}
+
+    def step():
+        last["res"] = be.epoch(W0, hop, sigma, gamma, "compact", False, keep_on_device=True)
+
+    elapsed, phases = h.timed_epochs(be, step, h.args.warmup, h.args.steps)
+    if algorithm != "exact":
+        ms = (ctypes.c_double * 5)()
+        _native.call("dbgsom_bmu_filtered_stage_ms", ms)
+        stage = dict(zip(("slice_w", "prepass", "bucket_sort", "sweep", "exact_on_candidates"),
+                         [float(v) for v in ms]))
+        _native.call("dbgsom_filter_timing", 0)
+        counts = be.filter_counts()
+        stage["candidates_per_workgroup"] = {"mean": float(counts.mean()),
+                                             "p90": float(np.percentile(counts, 90)),
+                                             "max": int(counts.max())}
+    wsum = float(last["res"].new_weights_dev.sum().item())
+    be.release()
+    return elapsed, phases, stage, wsum
+
+
+def fine_phase_regime(h, X, W0, M, d, hop, gamma):
     """Secondary measurement: epochs of the FINE training phase (BaseSom.py:395-396, 899-900:
     constant sigma_end = max(0.7, 0.05 sqrt(M)), no growth) on a map that a decaying-sigma
     warm-up has organised, prototypes evolving from step to step as in training.  Timed for the
-    exact search and for the filtered search (int8-MFMA candidate filter seeded with the previous
-    epoch's winners + exact float64 on the candidates; identical results).  Uses
+    exact search and for "auto" (previous winners as the filter's starting point).  Uses
     centres_layout="aligned": with the reference's compacted centre rows (quirk Q1) a 32x32 map
-    with dead neurons scrambles itself into near-duplicate prototypes (the headline regime above
-    does exactly that), which is not what a trained map looks like."""
+    with dead neurons scrambles itself into near-duplicate prototypes, which is not what a
+    trained map looks like."""
     from dbgsom_amd.backend import HipBackend
 
     sig0, sig1 = 0.2 * np.sqrt(M), max(0.7, 0.05 * np.sqrt(M))
     schedule = [sig1 + (sig0 - sig1) * np.exp(-0.35 * e) for e in range(14)]
     out = {"sigma": sig1, "warmup_epochs": len(schedule), "centres_layout": "aligned"}
-    for algo in ("exact", "filtered"):
-        be = HipBackend(local, algorithm=algo)
+    wsum = {}
+    for algo in ("exact", "auto"):
+        be = HipBackend(h.local, algorithm=algo)
         be.load_device(X)
-        W = ctl[:M * d].reshape(M, d).clone()
+        state = {"W": W0.clone()}
         for s_ in schedule:  # untimed: organise the map
-            W = be.epoch(W, hop, s_, gamma, "aligned", False, keep_on_device=True).new_weights_dev
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            res = be.epoch(W, hop, sig1, gamma, "aligned", False, keep_on_device=True)
-            W = res.new_weights_dev
-        sync()
-        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=X.device)
-        if td.is_initialized():
-            td.all_reduce(el, op=td.ReduceOp.MAX)
-        el = float(el.item())
-        out[algo] = {"ms_per_step": el / args.steps * 1e3,
-                     "value": X.shape[0] * world * args.steps / el,
-                     "dead_neurons": int((res.activations == 0).sum())}
-        if algo == "filtered":
+            state["W"] = be.epoch(state["W"], hop, s_, gamma, "aligned", False,
+                                  keep_on_device=True).new_weights_dev
+
+        def step():
+            state["res"] = be.epoch(state["W"], hop, sig1, gamma, "aligned", False,
+                                    keep_on_device=True)
+            state["W"] = state["res"].new_weights_dev
+
+        elapsed, _ = h.timed_epochs(be, step, 0, h.args.steps)
+        out[algo] = {"ms_per_step": elapsed / h.args.steps * 1e3,
+                     "value": X.shape[0] * h.world * h.args.steps / elapsed,
+                     "dead_neurons": int((state["res"].activations == 0).sum())}
+        if algo != "exact":
             c = be.filter_counts()
             out[algo]["candidates_per_workgroup"] = {"mean": float(c.mean()),
                                                      "p90": float(np.percentile(c, 90)),
                                                      "max": int(c.max())}
-            out[algo]["checksum_equal_to_exact"] = bool(
-                abs(float(W.sum().item()) - out["_wsum"]) == 0.0)
-        else:
-            out["_wsum"] = float(W.sum().item())
+        wsum[algo] = float(state["W"].sum().item())
         be.release()
-    out.pop("_wsum", None)
+    out["prototypes_identical"] = wsum["exact"] == wsum["auto"]
     return out
 
 
@@ -154,9 +228,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--samples-per-gpu", type=int, default=None, help="override N per GPU")
+    ap.add_argument("--algorithm", default="filtered", choices=["filtered", "exact"],
+                    help="BMU search of the headline value (both give identical results)")
     ap.add_argument("--fine-phase", type=int, default=1,
                     help="also time a trained map in the fine phase (sigma_end, evolving W) with "
-                         "the exact and the filtered search (0 disables)")
+                         "the exact and the hinted filtered search (0 disables)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="upper bound of rows timed by the CPU baseline (0 disables it); the "
                          "actual sample is sized for ~15 s of CPU work")
@@ -164,8 +240,6 @@ def main():
 
     import torch
     import torch.distributed as td
-
-    from dbgsom_amd.backend import HipBackend
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,16 +259,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    h = Harness(torch, td, args, local, world, grouped)
 
     n_gpu, d, rows, cols, seed, cfg_name = WORKLOADS[args.workload]
     if args.samples_per_gpu:
         n_gpu = args.samples_per_gpu
     M = rows * cols
-    # headline: the exact all-pairs float64 search -- its time does not depend on the data or on
-    # anything a previous step left behind
-    hip = HipBackend(local, algorithm="exact")
     X = make_shard(torch, n_gpu, d, seed + rank, device)
-    hip.load_device(X)
 
     # frozen map: M rows of rank 0's shard, Manhattan hop distances, epoch-0 sigma, gamma = 1/var
     ctl = torch.zeros(M * d + 1, dtype=torch.float64, device=device)
@@ -205,46 +276,39 @@ def main():
         ctl[M * d] = 1.0 / X.double().var(dim=0, unbiased=False).sum()
     if grouped:
         td.broadcast(ctl, 0)
-    W = ctl[:M * d].reshape(M, d).cpu().numpy()
+    W0 = ctl[:M * d].reshape(M, d).contiguous()
     gamma = float(ctl[M * d].item())
     hop = lattice_hops(rows, cols)
     sigma = 0.2 * np.sqrt(M)  # BaseSom.py:876 at epoch 0
 
-    def sync():
-        if grouped:
-            td.barrier()
-        torch.cuda.synchronize()
-
-    hip.kernel_events = None
-    # prototypes stay in HBM between steps (a training phase without growth); the per-neuron
-    # errors, hit counts and the convergence norm come back to the host every step
-    for _ in range(args.warmup):
-        W = hip.epoch(W, hop, sigma, gamma, "compact", False, keep_on_device=True).new_weights_dev
-    hip.kernel_events = []  # HIP events around the BMU and accumulate launches (their stream)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        W = hip.epoch(W, hop, sigma, gamma, "compact", False, keep_on_device=True).new_weights_dev
-    sync()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if grouped:
-        td.all_reduce(tmax, op=td.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-
-    ev = hip.kernel_events
-    fine = None
-    if args.fine_phase:
-        fine = fine_phase_regime(torch, td, args, X, ctl, M, d, hop, gamma, local, world, sync)
-    bmu_ms = float(np.mean([a.elapsed_time(b) for (k, a, b) in ev if k == "bmu"]))
-    acc_ms = float(np.mean([a.elapsed_time(b) for (k, a, b) in ev if k == "accumulate"]))
-    smooth_ms = float(np.mean([a.elapsed_time(b) for (k, a, b) in ev if k == "smooth"]))
-    hip.kernel_events = None
+    results = {}
+    for algo in dict.fromkeys([args.algorithm, "exact"]):  # headline first, exact always reported
+        results[algo] = frozen_map_regime(h, algo, X, W0, hop, sigma, gamma)
+    fine = fine_phase_regime(h, X, W0, M, d, hop, gamma) if args.fine_phase else None
 
     if rank == 0:
         total = n_gpu * world
-        flops = 2.0 * n_gpu * M * d  # algorithmic flops of one BMU launch
-        achieved = flops / (bmu_ms * 1e-3) / 1e12
+        elapsed, phases, stage, wsum = results[args.algorithm]
+        e_elapsed, e_phases, _, e_wsum = results["exact"]
+        flops = 2.0 * n_gpu * M * d  # algorithmic flops of one BMU search
+        e_ach = flops / (e_phases["bmu"] * 1e-3) / 1e12
+        exact_roof = {"bound": "mfma", "kernel": "bmu_dma_kernel<float,1>", "dtype": "f64",
+                      "achieved": e_ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": e_ach / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                      "kernel_ms": e_phases["bmu"]}
+        if args.algorithm == "exact":
+            roof = exact_roof
+        else:
+            dpad = (d + 63) // 64 * 64
+            ops = 2.0 * n_gpu * M * dpad * 6  # six int8 digit products per (sample, prototype, k)
+            ach = ops / (stage["sweep"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "sweep_i8_kernel<0>", "dtype": "i8",
+                    "achieved": ach, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                    "frac": ach / I8_MFMA_PEAK_TOPS,
+                    "traffic": SWEEP_TRAFFIC_C4_BYTES if args.workload == "c4" and
+                    n_gpu == WORKLOADS["c4"][0] else None,
+                    "kernel_ms": stage["sweep"],
+                    "algorithmic_equiv_TFLOPs": flops / (stage["sweep"] * 1e-3) / 1e12}
         out = {
             "metric": "samples/sec/epoch (BMU+update)",
             "value": total * args.steps / elapsed,
@@ -259,21 +323,24 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": cfg_name, "samples_per_gpu": n_gpu, "features": d,
-                       "prototypes": M, "x_storage": "f32", "sharding": f"rows/{world}"},
-            "roofline": {"bound": "mfma", "kernel": "bmu_dma_kernel<float,1>", "achieved": achieved,
-                         "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel_ms": bmu_ms},
-            "phases_ms": {"bmu": bmu_ms, "accumulate": acc_ms, "smooth": smooth_ms,
-                          "accumulate_GBps": n_gpu * d * 4 / (acc_ms * 1e-3) / 1e9},
+                       "prototypes": M, "x_storage": "f32", "sharding": f"rows/{world}",
+                       "map": "frozen (same prototypes every step)",
+                       "bmu_algorithm": args.algorithm},
+            "roofline": roof,
+            "phases_ms": dict(phases, accumulate_GBps=n_gpu * d * 4 / (phases["accumulate"] * 1e-3) / 1e9),
         }
-        if args.fine_phase:
+        if stage:
+            out["filter_stages_ms"] = stage
+        out["exact"] = {"value": total * args.steps / e_elapsed,
+                        "ms_per_step": e_elapsed / args.steps * 1e3, "phases_ms": e_phases,
+                        "roofline": exact_roof,
+                        "prototypes_identical_to_headline": e_wsum == wsum}
+        if fine:
             out["fine_phase"] = fine
         if args.cpu_sample > 0:
             ns = min(args.cpu_sample, n_gpu)
-            Xs = X[:ns].cpu().numpy()
-            W0 = ctl[:M * d].reshape(M, d).cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(args.workload, Xs, W0, hop, sigma, gamma, n_gpu)
+            out["cpu_baseline"] = cpu_baseline(args.workload, X[:ns].cpu().numpy(),
+                                               W0.cpu().numpy(), hop, sigma, gamma, n_gpu)
             out["gpu_vs_cpu"] = (n_gpu * args.steps / elapsed) / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if grouped:

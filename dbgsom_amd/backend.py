@@ -194,12 +194,19 @@ class HipBackend(HotPathBackend):
     FILTER_BACKOFF = 8
 
     def __init__(self, device: Optional[int] = None, algorithm: str = "auto"):
-        """algorithm: "exact" = all-pairs float64 MFMA search every epoch; "filtered" / "auto" =
-        int8-MFMA candidate filter + exact float64 on the candidates (identical results) whenever
-        it applies (float32 samples, d % 16 == 0, a previous epoch's winners, M >= 256)."""
+        """algorithm (all give IDENTICAL results):
+          "exact"          all-pairs float64 MFMA search;
+          "filtered"       stateless: coarse int8-MFMA pre-pass -> int8 candidate sweep -> exact
+                           float64 search on the candidates; nothing from earlier epochs is used;
+          "filtered_hint"  the same, but the previous epoch's winners replace the pre-pass when
+                           they are available (training: they almost always still win);
+          "auto"           "filtered_hint" with a back-off to "exact" while the candidate lists are
+                           long (maps of near-duplicate prototypes).
+        The filtered forms apply to float32 samples with d % 16 == 0 and 256 <= M <= 16000;
+        otherwise the exact kernel runs."""
         self._lib = _native.load()  # raises when the extension is not built
-        if algorithm not in ("auto", "exact", "filtered"):
-            raise ValueError("algorithm must be 'auto', 'exact' or 'filtered'")
+        if algorithm not in ("auto", "exact", "filtered", "filtered_hint"):
+            raise ValueError("algorithm must be 'auto', 'exact', 'filtered' or 'filtered_hint'")
         self.algorithm = algorithm
         self._init_args = (device, algorithm)
         import torch
@@ -316,11 +323,16 @@ class HipBackend(HotPathBackend):
     def _filter_applies(self, M):
         if self.algorithm == "auto" and self._filter_backoff > 0:
             return False
-        return (self.algorithm != "exact" and self._prev_idx is not None
-                and self._order is not None and not isinstance(self._x_np_dtype, str)
+        return (self.algorithm != "exact" and not isinstance(self._x_np_dtype, str)
                 and self._x_np_dtype == np.float32 and self._X.shape[1] % 16 == 0
-                and self.FILTER_MIN_PROTOTYPES <= M <= _native.MAX_PROTOTYPES
-                and self._prev_idx.numel() == self._X.shape[0])
+                and self.FILTER_MIN_PROTOTYPES <= M <= _native.MAX_PROTOTYPES)
+
+    def _hint(self):
+        """(previous winners, their bucket order) when the algorithm may use them."""
+        if (self.algorithm in ("auto", "filtered_hint") and self._prev_idx is not None
+                and self._order is not None and self._prev_idx.numel() == self._X.shape[0]):
+            return self._p(self._prev_idx), self._p(self._order)
+        return None, None
 
     def _bmu_filtered_dev(self, Wd, wwd, round_f32):
         torch = self._torch
@@ -335,9 +347,10 @@ class HipBackend(HotPathBackend):
         dist = torch.empty((N, 1), dtype=torch.float64, device=self.device)
         need = self._lib.dbgsom_bmu_filtered_workspace_bytes(N, d, M)
         ws = self._buf("filter", need)
+        prev_p, order_p = self._hint()
         self._timed_call("bmu", "dbgsom_bmu_filtered", self._p(self._X), _native.F32, N, d, d,
                          self._p(self._xx), self._p(self._planes), self._p(Wd), M, self._p(wwd),
-                         self._p(self._prev_idx), self._p(self._order), round_f32, self._p(idx),
+                         prev_p, order_p, round_f32, self._p(idx),
                          self._p(dist), self._p(ws), ws.numel(), self._stream())
         return dist, idx
 

@@ -307,6 +307,35 @@ __global__ __launch_bounds__(AT) void finalize_kernel(const double *__restrict__
     if (threadIdx.x == 0) ap[j] = (double)count[j];
 }
 
+// Stable bucket order of the samples by winner, on its own (the filtered BMU search visits the
+// samples in this order).  `ws` needs bucket_sort_workspace_bytes(N, M); `order` gets N int32.
+size_t bucket_sort_workspace_bytes(int64_t N, int64_t M) {
+    const int64_t nb = (N + HS - 1) / HS;
+    return align_up((size_t)nb * M * 4) + align_up((size_t)M * 4) + 2 * align_up((size_t)(M + 1) * 4);
+}
+
+int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order, void *ws,
+                       hipStream_t s) {
+    const int64_t nb = (N + HS - 1) / HS;
+    char *base = (char *)ws;
+    uint32_t *blk = (uint32_t *)base;
+    base += align_up((size_t)nb * M * 4);
+    uint32_t *count = (uint32_t *)base;
+    base += align_up((size_t)M * 4);
+    uint32_t *seg_start = (uint32_t *)base;
+    base += align_up((size_t)(M + 1) * 4);
+    uint32_t *chunk_pre = (uint32_t *)base;
+    const int Mi = (int)M;
+    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)nb), dim3(AT), (size_t)M * 4, s, idx, N, Mi, blk,
+                       (int32_t *)nullptr);
+    hipLaunchKernelGGL(colscan_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, blk, nb,
+                       Mi, count);
+    hipLaunchKernelGGL(segscan_kernel, dim3(1), dim3(1024), 0, s, count, Mi, seg_start, chunk_pre);
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nb), dim3(AT), (size_t)M * 4, s, idx, N, Mi,
+                       blk, seg_start, order);
+    return launch_status("bucket sort kernels");
+}
+
 // ---------------------------------------------------------------------------------------------
 int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                       const int64_t *idx, const double *kw, const double *dist, int64_t M,

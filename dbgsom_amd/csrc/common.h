@@ -67,6 +67,9 @@ size_t accumulate_workspace_bytes(int64_t N, int64_t d, int64_t M);
 int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                       const int64_t *idx, const double *kw, const double *dist, int64_t M,
                       double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s);
+size_t bucket_sort_workspace_bytes(int64_t N, int64_t M);
+int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order, void *ws,
+                       hipStream_t s);
 size_t smooth_workspace_bytes(int64_t M, int64_t d);
 int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, double sigma,
                   int layout, const double *W_old, double *W_new, double *change_total, void *ws,

@@ -138,13 +138,24 @@ constexpr int SW_OFF_MASK = SW_OFF_PREV + 128 * 4;
 constexpr int SW_MAX_M = 16000;
 constexpr int SW_SMEM = SW_OFF_MASK + (SW_MAX_M + 31) / 32 * 4 + 64;
 
+// MODE 0 (mark): the sweep described above -- six digit products, samples in bucket order of
+//   `prev`, candidate prototypes of every 128-sample workgroup written to ulist / ucount.
+// MODE 1 (seed): a cheaper pre-pass when there is no previous winner to start from: the three
+//   digit products with a + b <= 1 (two planes per operand), natural sample order
+//   (order == nullptr), output seed[i] = arg-min of that coarser r~ -- any index is a valid
+//   starting point for MODE 0, a near-minimal one keeps its candidate lists short.
+template <int MODE>
 __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx,
     const double *__restrict__ l1x, const double *__restrict__ xx, int64_t N, int d, int dpad,
     const int8_t *__restrict__ wplanes, const double *__restrict__ ww,
     const double *__restrict__ ctab, const double *__restrict__ summary, int M,
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
-    uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount) {
+    uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount,
+    int64_t *__restrict__ seed) {
+    constexpr int NPL = (MODE == 0) ? 3 : 2;       // digit planes used per operand
+    constexpr int NLV = (MODE == 0) ? 3 : 2;       // accumulator levels
+    constexpr int DMA_TILE = 2 * NPL;              // DMA instructions per wave per tile
     __shared__ __attribute__((aligned(16))) char smem[SW_SMEM];
     double *thr_s = reinterpret_cast<double *>(smem + SW_OFF_THR);
     int *prev_s = reinterpret_cast<int *>(smem + SW_OFF_PREV);
@@ -159,26 +170,31 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const int64_t p0 = (int64_t)blockIdx.x * 128;  // first sorted position of this workgroup
     const int nwords = (M + 31) / 32;
 
-    for (int w = tid; w < nwords; w += FNT) mask[w] = 0u;
-    if (tid < 128) {
-        const int64_t p = p0 + tid;
-        int pj = -1;
-        if (p < N) pj = (int)prev[order[p]];
-        prev_s[tid] = (pj >= 0 && pj < M) ? pj : -1;
-        thr_s[tid] = (p < N) ? INFINITY : -INFINITY;  // no bound yet / padding never marks
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int lo = 0x7fffffff, hi = -1;
-        for (int u = 0; u < 128; ++u) {
-            const int pj = prev_s[u];
-            if (pj >= 0) { lo = min(lo, pj); hi = max(hi, pj); }
+    auto sample_at = [&](int64_t p) -> int64_t { return order ? (int64_t)order[p] : p; };
+    int jlo = 0, jhi = -1;
+    if constexpr (MODE == 0) {
+        for (int w = tid; w < nwords; w += FNT) mask[w] = 0u;
+        if (tid < 128) {
+            const int64_t p = p0 + tid;
+            int pj = -1;
+            if (p < N) pj = (int)prev[sample_at(p)];
+            prev_s[tid] = (pj >= 0 && pj < M) ? pj : -1;
+            thr_s[tid] = (p < N) ? INFINITY : -INFINITY;  // no bound yet / padding never marks
         }
-        misc[0] = (hi >= 0) ? lo : 0;
-        misc[1] = hi;
+        __syncthreads();
+        if (tid == 0) {
+            int lo = 0x7fffffff, hi = -1;
+            for (int u = 0; u < 128; ++u) {
+                const int pj = prev_s[u];
+                if (pj >= 0) { lo = min(lo, pj); hi = max(hi, pj); }
+            }
+            misc[0] = (hi >= 0) ? lo : 0;
+            misc[1] = hi;
+        }
+        __syncthreads();
+        jlo = misc[0];
+        jhi = misc[1];
     }
-    __syncthreads();
-    const int jlo = misc[0], jhi = misc[1];
 
     // per-lane sample constants (2 samples: one per 32-column tile)
     double s_i[2], xx_i[2], eps2_i[2], thr_i[2];
@@ -188,20 +204,26 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     for (int it = 0; it < 2; ++it) {
         const int il = wi * 64 + it * 32 + lc;
         const int64_t p = p0 + il;
-        const int64_t i = (p < N) ? order[p] : order[N - 1];
+        const int64_t i = sample_at(p < N ? p : N - 1);
         s_i[it] = sx[i];
         xx_i[it] = xx[i];
-        eps2_i[it] = 2.0 * filter_eps(s_i[it], l1x[i], xx_i[it], l1w_max, t_max, yy_max, d);
-        prev_i[it] = prev_s[il];
-        thr_i[it] = thr_s[il];
+        if constexpr (MODE == 0) {
+            eps2_i[it] = 2.0 * filter_eps(s_i[it], l1x[i], xx_i[it], l1w_max, t_max, yy_max, d);
+            prev_i[it] = prev_s[il];
+            thr_i[it] = thr_s[il];
+        } else {
+            eps2_i[it] = 0.0; prev_i[it] = -1; thr_i[it] = 0.0;
+        }
     }
+    double bestv[2] = {INFINITY, INFINITY};  // MODE 1: running arg-min of the coarse r~
+    int bestj[2] = {0, 0};
 
     // ---- DMA sources: wave w loads, per plane, X rows 16w..16w+15 and W rows 16w..16w+15 -------
     const int dr = 16 * wave + (lane >> 2), dcp = lane & 3;
     const int dc = dcp ^ ((dr >> 2) & 3);  // source chunk for the linear LDS chunk (swizzle)
     const int64_t xpos = (p0 + dr < N) ? (p0 + dr) : (N - 1);
     const size_t xplane_stride = (size_t)N * dpad, wplane_stride = (size_t)M * dpad;
-    const int8_t *xsrc = xplanes + (size_t)order[xpos] * dpad + dc * 16;
+    const int8_t *xsrc = xplanes + (size_t)sample_at(xpos) * dpad + dc * 16;
     const int nkt = dpad / FKT;
     const int nchunk = (M + 127) / 128;
     const int ntile = nkt * nchunk;
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         jw = jw < M ? jw : M - 1;
         const int8_t *wsrc = wplanes + (size_t)jw * dpad + dc * 16 + k0;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
             fdma16(xsrc + p * xplane_stride + k0, stage + p * SW_PLANE + 1024 * wave);
             fdma16(wsrc + p * wplane_stride, stage + (3 + p) * SW_PLANE + 1024 * wave);
         }
@@ -239,11 +261,11 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         woff = 3 * SW_PLANE + r * FKT + ((lh ^ ((r >> 2) & 3)) * 16);
     }
     // chunk (2 ks + lh) ^ swz = (2 ks) ^ (lh ^ swz): k-step 1 flips bit 1 of the chunk -> byte 32
-    v16i_t acc[2][3];
+    v16i_t acc[2][NLV];
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
-        for (int L = 0; L < 3; ++L)
+        for (int L = 0; L < NLV; ++L)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[it][L][r] = 0;
 
@@ -252,8 +274,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 
     for (int t = 0; t < ntile; ++t) {
         if (t + 1 < ntile) {
-            if ((t + 1) % nkt == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if ((t + 1) % nkt == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_TILE + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_TILE) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -264,9 +286,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         const char *stage = smem + (t % FSTAGES) * SW_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            v4i_t xf[2][3], wf[3];
+            v4i_t xf[2][NPL], wf[NPL];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NPL; ++p) {
                 wf[p] = *reinterpret_cast<const v4i_t *>(stage + p * SW_PLANE + (woff ^ (ks * 32)));
 #pragma unroll
                 for (int it = 0; it < 2; ++it)
@@ -277,10 +299,12 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     acc[it][L] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[pw], xf[it][px], acc[it][L], 0, 0, 0)
             DBGSOM_I8(0, 0, 0, 0); DBGSOM_I8(1, 0, 0, 0);
             DBGSOM_I8(0, 0, 1, 1); DBGSOM_I8(1, 0, 1, 1);
-            DBGSOM_I8(0, 0, 2, 2); DBGSOM_I8(1, 0, 2, 2);
+            if constexpr (MODE == 0) { DBGSOM_I8(0, 0, 2, 2); DBGSOM_I8(1, 0, 2, 2); }
             DBGSOM_I8(0, 1, 0, 1); DBGSOM_I8(1, 1, 0, 1);
-            DBGSOM_I8(0, 1, 1, 2); DBGSOM_I8(1, 1, 1, 2);
-            DBGSOM_I8(0, 2, 0, 2); DBGSOM_I8(1, 2, 0, 2);
+            if constexpr (MODE == 0) {
+                DBGSOM_I8(0, 1, 1, 2); DBGSOM_I8(1, 1, 1, 2);
+                DBGSOM_I8(0, 2, 0, 2); DBGSOM_I8(1, 2, 0, 2);
+            }
 #undef DBGSOM_I8
         }
 
@@ -289,6 +313,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             const double *ytab = reinterpret_cast<const double *>(smem + SW_OFF_TAB + ((t / nkt) % 3) * 2 * SW_TAB);
             const double *ctb = ytab + 128;
             const bool has_prev = (jc <= jhi) && (jc + 127 >= jlo);
+            (void)has_prev;
             // r~ of the lane's 2 x 16 pairs
             double rv[2][16];
 #pragma unroll
@@ -296,36 +321,77 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int jl = wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const double T = ((double)acc[it][0][r] * 256.0 + (double)acc[it][1][r]) * 256.0 +
-                                     (double)acc[it][2][r];
+                    double T = (double)acc[it][0][r] * 256.0 + (double)acc[it][1][r];
+                    if constexpr (MODE == 0) T = T * 256.0 + (double)acc[it][2][r];
+                    else T = T * 256.0;
                     rv[it][r] = (xx_i[it] + ytab[jl]) - s_i[it] * (ctb[jl] * T);
                 }
-            if (has_prev) {  // bound from the previous winner: thr_i = r~(i, prev_i) + 2 eps_i
+            if constexpr (MODE == 0) {
+                if (has_prev) {  // bound from the starting prototype: thr_i = r~(i, prev_i) + 2 eps_i
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int j = jc + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            if (j == prev_i[it]) thr_s[wi * 64 + it * 32 + lc] = rv[it][r] + eps2_i[it];
+                        }
+                    __syncthreads();
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) thr_i[it] = thr_s[wi * 64 + it * 32 + lc];
+                }
 #pragma unroll
                 for (int it = 0; it < 2; ++it)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int j = jc + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (j == prev_i[it]) thr_s[wi * 64 + it * 32 + lc] = rv[it][r] + eps2_i[it];
+                        if (j < M && rv[it][r] <= thr_i[it]) atomicOr(&mask[j >> 5], 1u << (j & 31));
                     }
-                __syncthreads();
+            } else {
 #pragma unroll
-                for (int it = 0; it < 2; ++it) thr_i[it] = thr_s[wi * 64 + it * 32 + lc];
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = jc + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (j < M && rv[it][r] < bestv[it]) { bestv[it] = rv[it][r]; bestj[it] = j; }
+                    }
             }
 #pragma unroll
             for (int it = 0; it < 2; ++it)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = jc + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (j < M && rv[it][r] <= thr_i[it]) atomicOr(&mask[j >> 5], 1u << (j & 31));
-                }
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int L = 0; L < 3; ++L)
+                for (int L = 0; L < NLV; ++L)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[it][L][r] = 0;
         }
+    }
+
+    if constexpr (MODE == 1) {
+        // seed = arg-min of the coarse r~ over the 2 lane halves and the 4 prototype wavefronts
+        __syncthreads();
+        double *sv = reinterpret_cast<double *>(smem);          // [4][128]
+        int *sj = reinterpret_cast<int *>(smem + 4 * 128 * 8);  // [4][128]
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const double ov = __shfl_xor(bestv[it], 32, 64);
+            const int oj = __shfl_xor(bestj[it], 32, 64);
+            if (ov < bestv[it] || (ov == bestv[it] && oj < bestj[it])) { bestv[it] = ov; bestj[it] = oj; }
+            if (lh == 0) {
+                sv[wj * 128 + wi * 64 + it * 32 + lc] = bestv[it];
+                sj[wj * 128 + wi * 64 + it * 32 + lc] = bestj[it];
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && p0 + tid < N) {
+            double bv = sv[tid];
+            int bj = sj[tid];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const double ov = sv[w * 128 + tid];
+                const int oj = sj[w * 128 + tid];
+                if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+            }
+            seed[sample_at(p0 + tid)] = (int64_t)bj;
+        }
+        return;
     }
 
     // ---- compact the marked prototypes, ascending ------------------------------------------------
@@ -522,6 +588,9 @@ struct FilterWs {
     double *ctab, *yypad, *summary;
     uint16_t *ulist;
     uint32_t *ucount;
+    int64_t *seed;     // N   arg-min of the coarse pre-pass (when the caller has no previous winners)
+    int32_t *order;    // N   bucket order of the samples by seed
+    void *sort_ws;
     int64_t nb, Mpad;
 };
 static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_t M) {
@@ -530,10 +599,13 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o0 = take((size_t)Mpad * 8), o1 = take((size_t)Mpad * 8), o2 = take(64);
     const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
+    const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
+    const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
     if (f) {
         f->ctab = (double *)(base + o0); f->yypad = (double *)(base + o1);
         f->summary = (double *)(base + o2); f->ulist = (uint16_t *)(base + o3);
-        f->ucount = (uint32_t *)(base + o4); f->nb = nb; f->Mpad = Mpad;
+        f->ucount = (uint32_t *)(base + o4); f->seed = (int64_t *)(base + o5);
+        f->order = (int32_t *)(base + o6); f->sort_ws = base + o7; f->nb = nb; f->Mpad = Mpad;
     }
     return off;
 }
@@ -555,7 +627,40 @@ static int launch_slice(const void *A, int dtype, int64_t rows, int64_t d, int64
 
 using namespace dbgsom;
 
+// optional per-stage timing of dbgsom_bmu_filtered (bench / profiling): events on the caller's stream
+namespace {
+struct StageTimer {
+    bool enabled = false, valid = false;
+    hipEvent_t ev[6] = {};
+    bool created = false;
+    void mark(int k, hipStream_t s) {
+        if (!enabled) return;
+        if (!created) { for (auto &e : ev) (void)hipEventCreate(&e); created = true; }
+        (void)hipEventRecord(ev[k], s);
+    }
+};
+thread_local StageTimer g_timer;
+}  // namespace
+
 extern "C" {
+
+/* diagnostics: when enabled, dbgsom_bmu_filtered records HIP events between its stages;
+ * dbgsom_bmu_filtered_stage_ms returns their durations for the LAST call, in milliseconds:
+ * [0] slice W + tables, [1] coarse pre-pass (0 when a hint was given), [2] bucket sort,
+ * [3] int8 sweep, [4] exact search on the candidates. */
+int dbgsom_filter_timing(int enable) { g_timer.enabled = enable != 0; g_timer.valid = false; return DBGSOM_OK; }
+
+int dbgsom_bmu_filtered_stage_ms(double *ms5) {
+    DBGSOM_REQUIRE(ms5, "null pointer");
+    if (!g_timer.enabled || !g_timer.valid) { set_error("no timed dbgsom_bmu_filtered call"); return DBGSOM_ESTATE; }
+    DBGSOM_HIP_CHECK(hipEventSynchronize(g_timer.ev[5]));
+    for (int k = 0; k < 5; ++k) {
+        float ms = 0.f;
+        DBGSOM_HIP_CHECK(hipEventElapsedTime(&ms, g_timer.ev[k], g_timer.ev[k + 1]));
+        ms5[k] = ms;
+    }
+    return DBGSOM_OK;
+}
 
 size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d) {
     if (rows < 1 || d < 1) return 0;
@@ -590,8 +695,10 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     DBGSOM_REQUIRE(x_dtype == DBGSOM_F32, "the filtered search takes float32 samples");
     DBGSOM_REQUIRE(N >= 1 && N < 0x7fffffff && d >= 1 && d % KT == 0 && ldx >= d, "bad sample shape (d must be a multiple of 16)");
     DBGSOM_REQUIRE(M >= 1 && M <= SW_MAX_M, "M outside [1, 16000]");
-    DBGSOM_REQUIRE(X_dev && xx_dev && xplanes_dev && W_dev && ww_dev && prev_idx_dev && order_dev &&
-                       idx_dev && dist_dev && workspace_dev, "null pointer");
+    DBGSOM_REQUIRE(X_dev && xx_dev && xplanes_dev && W_dev && ww_dev && idx_dev && dist_dev &&
+                       workspace_dev, "null pointer");
+    DBGSOM_REQUIRE((prev_idx_dev == nullptr) == (order_dev == nullptr),
+                   "prev_idx and order come as a pair (both NULL = stateless two-pass search)");
     DBGSOM_REQUIRE(is_aligned(X_dev, 16) && (ldx * 4) % 16 == 0 && is_aligned(W_dev, 16) &&
                        is_aligned(workspace_dev, 256) && is_aligned(xplanes_dev, 256), "alignment");
     if (workspace_bytes < dbgsom_bmu_filtered_workspace_bytes(N, d, M)) {
@@ -604,16 +711,36 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     FilterWs f;
     carve_filter(&f, (char *)workspace_dev, N, d, M);
     const int dpad = (int)filter_dpad(d);
+    g_timer.mark(0, s);
     int rc = launch_slice(W_dev, DBGSOM_F64, M, d, d, f.w, s);
     if (rc != DBGSOM_OK) return rc;
     hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.w.scale, f.w.l1, ww_dev, (int)M,
                        (int)f.Mpad, f.ctab, f.yypad, f.summary);
-    hipLaunchKernelGGL(sweep_i8_kernel, dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes, xb.scale,
+    g_timer.mark(1, s);
+    if (!prev_idx_dev) {
+        // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
+        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
+                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab,
+                           f.summary, (int)M, (const int64_t *)nullptr, (const int32_t *)nullptr,
+                           f.ulist, (int)f.Mpad, f.ucount, f.seed);
+        g_timer.mark(2, s);
+        rc = launch_bucket_sort(f.seed, N, M, f.order, f.sort_ws, s);
+        if (rc != DBGSOM_OK) return rc;
+        prev_idx_dev = f.seed;
+        order_dev = f.order;
+    } else {
+        g_timer.mark(2, s);
+    }
+    g_timer.mark(3, s);
+    hipLaunchKernelGGL(sweep_i8_kernel<0>, dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes, xb.scale,
                        xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab, f.summary, (int)M,
-                       prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount);
+                       prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount, (int64_t *)nullptr);
+    g_timer.mark(4, s);
     hipLaunchKernelGGL(subset_exact_kernel, dim3((unsigned)f.nb), dim3(NT), 0, s,
                        (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev,
                        f.ulist, (int)f.Mpad, f.ucount, round_f32, idx_dev, dist_dev);
+    g_timer.mark(5, s);
+    g_timer.valid = g_timer.enabled;
     return launch_status("filtered bmu kernels");
 }
 

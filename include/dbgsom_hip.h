@@ -119,7 +119,10 @@ int dbgsom_smooth(const double *sums_dev, int64_t M, int64_t d, const float *hop
  *   prev_idx_dev: N winners of the previous epoch (any valid indices < M keep the result exact;
  *                 good ones keep the candidate sets small)
  *   order_dev   : the N sample ids bucketed by prev_idx -- the first N int32 of the workspace of
- *                 the previous dbgsom_accumulate call */
+ *                 the previous dbgsom_accumulate call
+ *   prev_idx_dev = order_dev = NULL: stateless form -- a coarser int8 pre-pass (three digit
+ *                 products) finds a starting prototype per sample and the samples are bucketed
+ *                 by it; nothing from an earlier call is used. */
 size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d);
 int dbgsom_filter_prepare(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                           void *planes_dev, size_t planes_bytes, void *stream);
@@ -130,6 +133,10 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                         const int32_t *order_dev, int round_f32, int64_t *idx_dev,
                         double *dist_dev, void *workspace_dev, size_t workspace_bytes,
                         void *stream);
+/* diagnostics: per-stage HIP-event timing of dbgsom_bmu_filtered on the caller's stream.
+ * ms5 = [slice W + tables, coarse pre-pass, bucket sort, int8 sweep, exact search on candidates] */
+int dbgsom_filter_timing(int enable);
+int dbgsom_bmu_filtered_stage_ms(double *ms5);
 /* diagnostics: candidate-list length of every 128-sample workgroup of the last filtered call */
 int dbgsom_bmu_filtered_counts(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
                                uint32_t *counts_host, int64_t n_counts, void *stream);

@@ -360,22 +360,23 @@ def test_filtered_search_is_identical_to_exact(o, N, d, rows, cols):
     hop = gi.lattice_hops(rows, cols)
     gamma = float(1.0 / np.var(X, axis=0).sum())
     exact = HipBackend(algorithm="exact").load(X)
-    filt = HipBackend(algorithm="filtered").load(X)
+    filt = HipBackend(algorithm="filtered_hint").load(X)   # pre-pass at epoch 0, hints afterwards
+    stateless = HipBackend(algorithm="filtered").load(X)   # pre-pass every epoch
     sigma = 0.2 * np.sqrt(M)
     We, Wf = W, W
     for e in range(5):
         re_ = exact.epoch(We, hop, sigma, gamma, "compact", True)
         rf = filt.epoch(Wf, hop, sigma, gamma, "compact", True)
-        assert np.array_equal(re_.winners, rf.winners), f"epoch {e}"
-        assert np.array_equal(re_.distances, rf.distances), f"epoch {e}"
-        assert np.array_equal(re_.new_weights, rf.new_weights), f"epoch {e}"
+        rs = stateless.epoch(We, hop, sigma, gamma, "compact", True)
+        for r in (rf, rs):
+            assert np.array_equal(re_.winners, r.winners), f"epoch {e}"
+            assert np.array_equal(re_.distances, r.distances), f"epoch {e}"
+            assert np.array_equal(re_.new_weights, r.new_weights), f"epoch {e}"
         We, Wf = re_.new_weights, rf.new_weights
-        if e >= 1:
-            counts = filt.filter_counts()
-            assert counts.min() >= 1 and counts.max() <= M
+        counts = filt.filter_counts()
+        assert counts.min() >= 1 and counts.max() <= M
         sigma *= 0.6
-    # epoch 0 ran the exact kernel (no previous winners); the others must have used the filter
-    assert filt._planes is not None
+    assert filt._planes is not None and stateless._planes is not None
     # oracle spot check of the last filtered epoch
     pick = np.random.default_rng(0).choice(N, 1500, replace=False)
     W_last_in = We if False else None  # (weights fed to the last epoch are not kept; check below)
@@ -395,10 +396,10 @@ def test_filtered_search_with_ties_and_bad_previous_winners(o):
     X = rng.integers(-3, 4, size=(N, d)).astype(np.float32)
     base = rng.integers(-3, 4, size=(M // 3, d)).astype(np.float64)
     W = np.concatenate([base, base, base])  # every prototype appears 3 times
-    be = HipBackend(algorithm="filtered").load(X)
+    be = HipBackend(algorithm="filtered_hint").load(X)
     hop = gi.lattice_hops(15, 20)
-    r0 = be.epoch(W, hop, 2.0, 0.01, "compact", True)      # exact kernel, sets the hint
-    r1 = be.epoch(W, hop, 2.0, 0.01, "compact", True)      # filtered, same W -> same answer
+    r0 = be.epoch(W, hop, 2.0, 0.01, "compact", True)      # stateless two-pass, sets the hint
+    r1 = be.epoch(W, hop, 2.0, 0.01, "compact", True)      # hinted, same W -> same answer
     assert np.array_equal(r0.winners, r1.winners) and np.array_equal(r0.distances, r1.distances)
     assert (r1.winners < M // 3).all()
     rd, ri = o.bmu_chain(X, W, 1)
@@ -429,6 +430,6 @@ def test_auto_policy_backs_off_on_near_duplicate_prototypes(o):
         q = ex.epoch(W, hop, 1.0, 1e-3, "aligned", True)
         assert np.array_equal(r.winners, q.winners) and np.array_equal(r.distances, q.distances)
         kinds.append(be.filter_log[-1][0])
-    assert kinds[0] == "exact" and kinds[1] == "filtered"   # probe once ...
-    assert kinds[2:] == ["exact"] * 3                        # ... then back off
-    assert be.filter_log[1][1] > HipBackend.FILTER_MAX_MEAN_CANDIDATES
+    assert kinds[0] == "filtered"                            # probe once ...
+    assert kinds[1:] == ["exact"] * 4                        # ... then back off
+    assert be.filter_log[0][1] > HipBackend.FILTER_MAX_MEAN_CANDIDATES

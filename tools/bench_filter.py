@@ -10,7 +10,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "c4"
 n, d, rows, cols, seed, _ = bench.WORKLOADS[name]
 M = rows * cols
 dev = torch.device("cuda", 0)
-hip = HipBackend(0, algorithm="filtered")
+hip = HipBackend(0, algorithm=os.environ.get("ALGO", "filtered"))
 X = bench.make_shard(torch, n, d, seed, dev)
 hip.load_device(X)
 g = torch.Generator(device=dev).manual_seed(seed + 7)
