@@ -44,7 +44,7 @@ F64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 cycles
 I8_MFMA_PEAK_TOPS = 5033.0   # 256 x 4 x 2.4 GHz x 65536 op / 32 cycles (v_mfma_i32_32x32x32_i8, dense)
 # HBM-side bytes of one sweep_i8_kernel<0> launch at C4 from the PMC pass committed under
 # profiles/ (FETCH_SIZE x 2 per the gfx950 correction); not measurable inside this process
-SWEEP_TRAFFIC_C4_BYTES = 2.63e10
+SWEEP_TRAFFIC_C4_BYTES = 2.42e10
 
 
 def lattice_hops(rows, cols):

@@ -1,0 +1,31 @@
+"""Profiling driver: N frozen-map epochs (bench workload) with a chosen BMU algorithm, nothing else.
+    rocprofv3 --pmc FETCH_SIZE -d out --output-format csv -- python3 tools/run_frozen.py c4 3 filtered"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from dbgsom_amd.backend import HipBackend  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "c4"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+algo = sys.argv[3] if len(sys.argv) > 3 else "filtered"
+n, d, rows, cols, seed, _ = bench.WORKLOADS[name]
+M = rows * cols
+dev = torch.device("cuda", 0)
+hip = HipBackend(0, algorithm=algo)
+X = bench.make_shard(torch, n, d, seed, dev)
+hip.load_device(X)
+g = torch.Generator(device=dev).manual_seed(seed + 7)
+W = X[torch.randperm(n, device=dev, generator=g)[:M]].double().contiguous()
+gamma = float(1.0 / X.double().var(dim=0, unbiased=False).sum().item())
+hop = bench.lattice_hops(rows, cols)
+for _ in range(steps):
+    hip.epoch(W, hop, 0.2 * np.sqrt(M), gamma, "compact", False, keep_on_device=True)
+torch.cuda.synchronize()
+print("done", name, steps, algo)
