@@ -95,51 +95,66 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(const float *__restr
     if (t == 0) den[i] = red[0];
 }
 
-// W'[i, c] = (sum_j G[i, j] C[j, c]) / den[i]   -- 64 x 64 tile per workgroup, 4 x 4 per thread,
-// j ascending inside one accumulator (sequential like the reference's np.sum over axis 1)
-constexpr int GT = 64, GK = 16;
+// W'[i, c] = (sum_j G[i, j] C[j, c]) / den[i] on the f64 matrix cores: 64 x 64 tile per
+// workgroup, 4 wavefronts of 2 x 2 v_mfma_f64_16x16x4_f64 tiles, j ascending inside one
+// accumulator chain (sequential like the reference's np.sum over axis 1)
+typedef double sd4_t __attribute__((ext_vector_type(4)));
+constexpr int GT = 64, GK = 16, GS_A = GK + 2, GS_B = GT + 16;
 __global__ __launch_bounds__(256) void smooth_gemm_kernel(const double *__restrict__ G,
                                                           const double *__restrict__ C,
                                                           const double *__restrict__ den, int M,
                                                           int d, double *__restrict__ Wn) {
-    __shared__ double gs[GT][GK + 1];
-    __shared__ double cs[GK][GT + 1];
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    __shared__ double gs[GT * GS_A];   // [i][j]   rows padded to 18: conflict-free A fragments
+    __shared__ double cs[GK * GS_B];   // [j][c]   rows padded to 80: conflict-free B fragments
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 wavefronts, 32 x 32 outputs each
+    const int lr = lane & 15, lq = lane >> 4;
     const int i0 = blockIdx.y * GT, c0 = blockIdx.x * GT;
-    double acc[4][4] = {};
+    sd4_t acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[u][v] = sd4_t{0.0, 0.0, 0.0, 0.0};
     for (int j0 = 0; j0 < M; j0 += GK) {
         __syncthreads();
         for (int e = t; e < GT * GK; e += 256) {
             const int r = e / GK, k = e % GK;  // G tile: 64 rows x 16 j
             const int gi = i0 + r, gj = j0 + k;
-            gs[r][k] = (gi < M && gj < M) ? G[(size_t)gi * M + gj] : 0.0;
+            gs[r * GS_A + k] = (gi < M && gj < M) ? G[(size_t)gi * M + gj] : 0.0;
             const int kr = e / GT, cc = e % GT;  // C tile: 16 j x 64 cols
             const int cj = j0 + kr, col = c0 + cc;
-            cs[kr][cc] = (cj < M && col < d) ? C[(size_t)cj * d + col] : 0.0;
+            cs[kr * GS_B + cc] = (cj < M && col < d) ? C[(size_t)cj * d + col] : 0.0;
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < GK; ++k) {
-            double gv[4], cv[4];
+        for (int ks = 0; ks < GK / 4; ++ks) {
+            double a[2], b[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { gv[u] = gs[ty * 4 + u][k]; cv[u] = cs[k][tx * 4 + u]; }
+            for (int u = 0; u < 2; ++u) {
+                a[u] = gs[(wr * 32 + u * 16 + lr) * GS_A + ks * 4 + lq];
+                b[u] = cs[(ks * 4 + lq) * GS_B + wc * 32 + u * 16 + lr];
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] += gv[u] * cv[v];
+                for (int v = 0; v < 2; ++v)
+                    acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
         }
     }
+    // D layout: reg r of lane l = D[row = (l >> 4) + 4 r][col = l & 15]
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = i0 + ty * 4 + u;
-        if (i >= M) continue;
-        const double dn = den[i];
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int c = c0 + tx * 4 + v;
-            if (c < d) Wn[(size_t)i * d + c] = acc[u][v] / dn;
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + wr * 32 + u * 16 + lq + 4 * r;
+            if (i >= M) continue;
+            const double dn = den[i];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int c = c0 + wc * 32 + v * 16 + lr;
+                if (c < d) Wn[(size_t)i * d + c] = acc[u][v][r] / dn;
+            }
         }
-    }
 }
 
 // rowchg[i] = |W_i - W'_i|_2
