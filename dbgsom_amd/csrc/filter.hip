@@ -421,8 +421,10 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 }
 
 // ---- 3. exact arg-min over the marked prototypes (float64 MFMA on gathered rows) -----------------
-constexpr int SJ = 32;   // prototypes per step
-constexpr int S_XT = 128 * KT * 4, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 KB + 4 KB
+// 128 gathered samples x SJ = 16 listed prototypes per step (the lists are short: a handful of
+// prototypes per workgroup on an organised map); 4 wavefronts x 32 samples, 3-stage LDS-DMA ring.
+constexpr int SJ = 16;
+constexpr int S_XT = 128 * KT * 4, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 KB + 2 KB
 
 __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     const float *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
@@ -462,8 +464,9 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         p = p < N ? p : N - 1;
         xsrc[u] = X + (int64_t)order[p] * ldx + c * 4;
     }
-    // W tile: 32 rows x 128 B, 4 instructions, wave w issues q = w: rows 8w..8w+7
-    const int wr = 8 * wave + (lane >> 3), wcp = lane & 7;
+    // W tile: 16 rows x 128 B = 2 instructions, issued by waves 0 and 1: rows 8w..8w+7
+    const bool w_loader = wave < 2;
+    const int wr = 8 * (wave & 1) + (lane >> 3), wcp = lane & 7;
     const int wc = (wcp ^ ((wr >> 1) & 7)) * 2;
 
     const int nkt = d / KT;
@@ -475,77 +478,72 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         char *stage = smem + (t % 3) * S_STAGE;
 #pragma unroll
         for (int u = 0; u < 2; ++u) fdma16(xsrc[u] + k0, stage + 1024 * (2 * wave + u));
-        int pos = st * SJ + wr;
-        pos = pos < cnt ? pos : cnt - 1;
-        const int j = (int)list[pos];
-        fdma16(W + (int64_t)j * d + k0 + wc, stage + S_XT + 1024 * wave);
+        if (w_loader) {
+            int pos = st * SJ + wr;
+            pos = pos < cnt ? pos : cnt - 1;
+            const int j = (int)list[pos];
+            fdma16(W + (int64_t)j * d + k0 + wc, stage + S_XT + 1024 * wave);
+        }
     };
 
-    int a_off[2], a_swz[2], b_off[2], b_swz[2];
+    const int a_off = S_XT + lr * 128 + (lq & 1) * 8, a_swz = (lr >> 1) & 7;
+    int b_off[2], b_swz[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int ra = u * 16 + lr;  // prototype row inside the 32-row step
-        a_off[u] = S_XT + ra * 128 + (lq & 1) * 8;
-        a_swz[u] = (ra >> 1) & 7;
         const int rb = wave * 32 + u * 16 + lr;
         b_off[u] = rb * 64 + lq * 4;
         b_swz[u] = (rb >> 1) & 3;
     }
 
-    d4_t acc[2][2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int it = 0; it < 2; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
+    d4_t acc[2] = {d4_t{0.0, 0.0, 0.0, 0.0}, d4_t{0.0, 0.0, 0.0, 0.0}};
 
     if (ntile > 0) issue(0);
     if (ntile > 1) issue(1);
     int kt = 0, st = 0;
     for (int t = 0; t < ntile; ++t) {
-        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // each wavefront waits for ITS OWN DMAs of tile t (3 per tile for the two that also load
+        // W, 2 for the others), the barrier then covers everybody's
+        if (t + 1 < ntile) {
+            if (w_loader) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 2 < ntile) issue(t + 2);
         const char *stage = smem + (t % 3) * S_STAGE;
 #pragma unroll
         for (int ks = 0; ks < KT / 4; ++ks) {
-            double a[2], b[2];
+            const int ca = (2 * ks + (lq >> 1)) ^ a_swz;
+            const double a = *reinterpret_cast<const double *>(stage + a_off + ca * 16);
+            double b[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int ca = (2 * ks + (lq >> 1)) ^ a_swz[u];
-                a[u] = *reinterpret_cast<const double *>(stage + a_off[u] + ca * 16);
                 const int cb = ks ^ b_swz[u];
                 b[u] = (double)*reinterpret_cast<const float *>(stage + b_off[u] + cb * 16);
             }
 #pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
-                    acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt], b[it], acc[jt][it],
-                                                                       0, 0, 0);
+            for (int it = 0; it < 2; ++it)
+                acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[it], acc[it], 0, 0, 0);
         }
         if (kt == nkt - 1) {
 #pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
+            for (int r = 0; r < 4; ++r) {
+                const int pos = st * SJ + 4 * r + lq;
+                if (pos < cnt) {
+                    const int j = (int)list[pos];
+                    const double y = ww[j];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pos = st * SJ + jt * 16 + 4 * r + lq;
-                    if (pos < cnt) {
-                        const int j = (int)list[pos];
-                        const double y = ww[j];
-#pragma unroll
-                        for (int it = 0; it < 2; ++it) {
-                            double rv = (xi[it] + (-2.0 * acc[jt][it][r])) + y;
-                            if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
-                            best[it].push(rv, j);  // list ascends -> j ascends per lane
-                        }
+                    for (int it = 0; it < 2; ++it) {
+                        double rv = (xi[it] + (-2.0 * acc[it][r])) + y;
+                        if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
+                        best[it].push(rv, j);  // list ascends -> j ascends per lane
                     }
                 }
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int it = 0; it < 2; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
+            }
+            acc[0] = d4_t{0.0, 0.0, 0.0, 0.0};
+            acc[1] = d4_t{0.0, 0.0, 0.0, 0.0};
             kt = 0;
             ++st;
         } else {
