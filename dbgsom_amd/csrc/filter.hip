@@ -75,16 +75,24 @@ __global__ __launch_bounds__(256) void slice_rows_kernel(const T *__restrict__ A
 // per-prototype tables of the sweep, padded with zeros to Mpad (a multiple of 128) entries:
 // ctab_j = 2 t_j 2^16 / F^2 (so r~ = (xx+yy) - s_i ctab_j T), yypad_j = |w_j|^2;
 // summary[0] = max_j l1_j, summary[1] = max_j t_j, summary[2] = max_j |w_j|^2
+// (ctab_sub, yy_sub: the same for every `stride`-th prototype -- the seed pre-pass)
 __global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict__ tw,
                                                        const double *__restrict__ l1w,
                                                        const double *__restrict__ ww, int M,
-                                                       int Mpad, double *__restrict__ ctab,
+                                                       int Mpad, int stride,
+                                                       double *__restrict__ ctab,
                                                        double *__restrict__ yypad,
+                                                       double *__restrict__ ctab_sub,
+                                                       double *__restrict__ yy_sub,
                                                        double *__restrict__ summary) {
     __shared__ double r0[1024], r1[1024], r2[1024];
     const int t = threadIdx.x;
     double a = 0.0, b = 0.0, c = 0.0;
     for (int j = t; j < Mpad; j += 1024) {
+        const long js = (long)j * stride;  // j-th entry of the strided tables
+        const bool in_sub = js < M;
+        ctab_sub[j] = in_sub ? 2.0 * tw[js] * 65536.0 / (FQ * FQ) : 0.0;
+        yy_sub[j] = in_sub ? ww[js] : 0.0;
         if (j >= M) { ctab[j] = 0.0; yypad[j] = 0.0; continue; }
         ctab[j] = 2.0 * tw[j] * 65536.0 / (FQ * FQ);
         yypad[j] = ww[j];
@@ -152,7 +160,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const double *__restrict__ ctab, const double *__restrict__ summary, int M,
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount,
-    int64_t *__restrict__ seed) {
+    int64_t *__restrict__ seed, int jstride, int w_rows) {
+    // jstride (MODE 1 only): the pre-pass looks at every jstride-th prototype; M is then the
+    // number of those and `ww` / `ctab` are the strided tables
     constexpr int NPL = (MODE == 0) ? 3 : 2;       // digit planes used per operand
     constexpr int NLV = (MODE == 0) ? 3 : 2;       // accumulator levels
     constexpr int DMA_TILE = 2 * NPL;              // DMA instructions per wave per tile
@@ -222,7 +232,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const int dr = 16 * wave + (lane >> 2), dcp = lane & 3;
     const int dc = dcp ^ ((dr >> 2) & 3);  // source chunk for the linear LDS chunk (swizzle)
     const int64_t xpos = (p0 + dr < N) ? (p0 + dr) : (N - 1);
-    const size_t xplane_stride = (size_t)N * dpad, wplane_stride = (size_t)M * dpad;
+    const size_t xplane_stride = (size_t)N * dpad;
+    const size_t wplane_stride = (size_t)w_rows * dpad;  // rows of one W plane (all prototypes)
     const int8_t *xsrc = xplanes + (size_t)sample_at(xpos) * dpad + dc * 16;
     const int nkt = dpad / FKT;
     const int nchunk = (M + 127) / 128;
@@ -235,6 +246,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         char *stage = smem + (t % FSTAGES) * SW_STAGE;
         int jw = jc_t + dr;
         jw = jw < M ? jw : M - 1;
+        if constexpr (MODE == 1) jw *= jstride;
         const int8_t *wsrc = wplanes + (size_t)jw * dpad + dc * 16 + k0;
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int j = jc + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (j < M && rv[it][r] < bestv[it]) { bestv[it] = rv[it][r]; bestj[it] = j; }
+                        if (j < M && rv[it][r] < bestv[it]) { bestv[it] = rv[it][r]; bestj[it] = j * jstride; }
                     }
             }
 #pragma unroll
@@ -583,7 +595,7 @@ static size_t carve_planes(PlaneBuf *b, char *base, int64_t rows, int64_t d) {
 
 struct FilterWs {
     PlaneBuf w;
-    double *ctab, *yypad, *summary;
+    double *ctab, *yypad, *ctab_sub, *yy_sub, *summary;
     uint16_t *ulist;
     uint32_t *ucount;
     int64_t *seed;     // N   arg-min of the coarse pre-pass (when the caller has no previous winners)
@@ -596,11 +608,13 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     size_t off = carve_planes(f ? &f->w : nullptr, base, M, d);
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o0 = take((size_t)Mpad * 8), o1 = take((size_t)Mpad * 8), o2 = take(64);
+    const size_t o8 = take((size_t)Mpad * 8), o9 = take((size_t)Mpad * 8);
     const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
     const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
     if (f) {
         f->ctab = (double *)(base + o0); f->yypad = (double *)(base + o1);
+        f->ctab_sub = (double *)(base + o8); f->yy_sub = (double *)(base + o9);
         f->summary = (double *)(base + o2); f->ulist = (uint16_t *)(base + o3);
         f->ucount = (uint32_t *)(base + o4); f->seed = (int64_t *)(base + o5);
         f->order = (int32_t *)(base + o6); f->sort_ws = base + o7; f->nb = nb; f->Mpad = Mpad;
@@ -687,9 +701,10 @@ size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M) {
 int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                         const double *xx_dev, const void *xplanes_dev, const double *W_dev,
                         int64_t M, const double *ww_dev, const int64_t *prev_idx_dev,
-                        const int32_t *order_dev, int round_f32, int64_t *idx_dev,
-                        double *dist_dev, void *workspace_dev, size_t workspace_bytes,
-                        void *stream) {
+                        const int32_t *order_dev, int seed_stride, int round_f32,
+                        int64_t *idx_dev, double *dist_dev, void *workspace_dev,
+                        size_t workspace_bytes, void *stream) {
+    DBGSOM_REQUIRE(seed_stride >= 0 && seed_stride <= 64, "seed_stride outside [0, 64]");
     DBGSOM_REQUIRE(x_dtype == DBGSOM_F32, "the filtered search takes float32 samples");
     DBGSOM_REQUIRE(N >= 1 && N < 0x7fffffff && d >= 1 && d % KT == 0 && ldx >= d, "bad sample shape (d must be a multiple of 16)");
     DBGSOM_REQUIRE(M >= 1 && M <= SW_MAX_M, "M outside [1, 16000]");
@@ -712,15 +727,20 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     g_timer.mark(0, s);
     int rc = launch_slice(W_dev, DBGSOM_F64, M, d, d, f.w, s);
     if (rc != DBGSOM_OK) return rc;
+    // the seed pre-pass looks at every `seed_stride`-th prototype (any seed keeps the result exact;
+    // a coarser pre-pass is cheaper, its seeds are a little further from the minimum)
+    if (seed_stride == 0) seed_stride = 4;
+    while (seed_stride > 1 && (M + seed_stride - 1) / seed_stride < 128) seed_stride >>= 1;
+    const int Msub = (int)((M + seed_stride - 1) / seed_stride);
     hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.w.scale, f.w.l1, ww_dev, (int)M,
-                       (int)f.Mpad, f.ctab, f.yypad, f.summary);
+                       (int)f.Mpad, seed_stride, f.ctab, f.yypad, f.ctab_sub, f.yy_sub, f.summary);
     g_timer.mark(1, s);
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
         hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
-                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab,
-                           f.summary, (int)M, (const int64_t *)nullptr, (const int32_t *)nullptr,
-                           f.ulist, (int)f.Mpad, f.ucount, f.seed);
+                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yy_sub, f.ctab_sub,
+                           f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
+                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, (int)M);
         g_timer.mark(2, s);
         rc = launch_bucket_sort(f.seed, N, M, f.order, f.sort_ws, s);
         if (rc != DBGSOM_OK) return rc;
@@ -732,7 +752,8 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     g_timer.mark(3, s);
     hipLaunchKernelGGL(sweep_i8_kernel<0>, dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes, xb.scale,
                        xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab, f.summary, (int)M,
-                       prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount, (int64_t *)nullptr);
+                       prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount, (int64_t *)nullptr, 1,
+                       (int)M);
     g_timer.mark(4, s);
     hipLaunchKernelGGL(subset_exact_kernel, dim3((unsigned)f.nb), dim3(NT), 0, s,
                        (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev,

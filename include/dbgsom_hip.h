@@ -121,8 +121,10 @@ int dbgsom_smooth(const double *sums_dev, int64_t M, int64_t d, const float *hop
  *   order_dev   : the N sample ids bucketed by prev_idx -- the first N int32 of the workspace of
  *                 the previous dbgsom_accumulate call
  *   prev_idx_dev = order_dev = NULL: stateless form -- a coarser int8 pre-pass (three digit
- *                 products) finds a starting prototype per sample and the samples are bucketed
- *                 by it; nothing from an earlier call is used. */
+ *                 products, every seed_stride-th prototype; 0 = default 4) finds a starting
+ *                 prototype per sample and the samples are bucketed by it; nothing from an earlier
+ *                 call is used.  The seed only sets the candidate threshold: ANY seed gives the
+ *                 exact result, a nearer one shorter candidate lists. */
 size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d);
 int dbgsom_filter_prepare(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                           void *planes_dev, size_t planes_bytes, void *stream);
@@ -130,9 +132,9 @@ size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M);
 int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                         const double *xx_dev, const void *xplanes_dev, const double *W_dev,
                         int64_t M, const double *ww_dev, const int64_t *prev_idx_dev,
-                        const int32_t *order_dev, int round_f32, int64_t *idx_dev,
-                        double *dist_dev, void *workspace_dev, size_t workspace_bytes,
-                        void *stream);
+                        const int32_t *order_dev, int seed_stride, int round_f32,
+                        int64_t *idx_dev, double *dist_dev, void *workspace_dev,
+                        size_t workspace_bytes, void *stream);
 /* diagnostics: per-stage HIP-event timing of dbgsom_bmu_filtered on the caller's stream.
  * ms5 = [slice W + tables, coarse pre-pass, bucket sort, int8 sweep, exact search on candidates] */
 int dbgsom_filter_timing(int enable);
