@@ -337,7 +337,7 @@ def main():
                         "prototypes_identical_to_headline": e_wsum == wsum}
         if fine:
             out["fine_phase"] = fine
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # the CPU baseline is reported at N = 1 only
             ns = min(args.cpu_sample, n_gpu)
             out["cpu_baseline"] = cpu_baseline(args.workload, X[:ns].cpu().numpy(),
                                                W0.cpu().numpy(), hop, sigma, gamma, n_gpu)
