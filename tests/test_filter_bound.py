@@ -1,0 +1,120 @@
+"""CPU check of the mathematics behind the filtered BMU search (dbgsom_amd/csrc/filter.hip):
+a NumPy emulation of the digit planes, the six int8 digit products and r~, against the exact
+distances, on random and adversarial rows -- the error must stay inside the bound the kernel uses
+(`filter_eps`), and the candidate rule must keep every prototype that can win or tie."""
+import numpy as np
+import pytest
+
+F = 127.0 * 65536.0
+
+
+def slice_rows(A):
+    A = np.asarray(A, dtype=np.float64)
+    s = np.abs(A).max(axis=1)
+    s[s == 0] = 1.0
+    Q = np.rint(A / s[:, None] * F).astype(np.int64)
+    d2 = ((Q + 128) & 255) - 128
+    q1 = (Q - d2) >> 8
+    d1 = ((q1 + 128) & 255) - 128
+    d0 = (q1 - d1) >> 8
+    assert np.abs(d0).max() <= 127 and np.abs(d1).max() <= 128 and np.abs(d2).max() <= 128
+    assert np.array_equal(d0 * 65536 + d1 * 256 + d2, Q)
+    return (d0, d1, d2), s, np.abs(A).sum(axis=1)
+
+
+def r_tilde(X, W, levels=3):
+    (x0, x1, x2), sx, l1x = slice_rows(X)
+    (w0, w1, w2), tw, l1w = slice_rows(W)
+    P0 = x0 @ w0.T
+    P1 = x0 @ w1.T + x1 @ w0.T
+    P2 = x0 @ w2.T + x1 @ w1.T + x2 @ w0.T
+    T = (P0 * 256 + P1) * 256 + (P2 if levels == 3 else 0)
+    xx = (X.astype(np.float64) ** 2).sum(axis=1)
+    yy = (W.astype(np.float64) ** 2).sum(axis=1)
+    ctab = 2.0 * tw * 65536.0 / (F * F)
+    return (xx[:, None] + yy[None, :]) - sx[:, None] * (ctab[None, :] * T.astype(np.float64)), \
+        (sx, l1x, xx, tw, l1w, yy)
+
+
+def filter_eps(s, l1x, xx, l1w_max, t_max, yy_max, d):
+    quant = (s * l1w_max + t_max * l1x) / (2.0 * F) + d * s * t_max / (4.0 * F * F)
+    dropped = d * (16384.0 * 513.0) * s * t_max / (F * F)
+    rounding = 4.0 * (d + 16) * 1.1102230246251565e-16 * (xx + yy_max)
+    return 2.0 * (quant + dropped) * (1.0 + 1e-7) + rounding
+
+
+def exact_r(X, W):
+    Xl, Wl = X.astype(np.longdouble), W.astype(np.longdouble)
+    return ((Xl ** 2).sum(1)[:, None] - 2 * (Xl @ Wl.T) + (Wl ** 2).sum(1)[None, :]).astype(np.float64)
+
+
+CASES = [
+    ("gauss", lambda rng: (rng.normal(size=(300, 96)).astype(np.float32), rng.normal(size=(80, 96)))),
+    ("blobs", lambda rng: (((rng.normal(size=(4, 64)) * 4)[rng.integers(0, 4, 400)]
+                            + rng.normal(size=(400, 64))).astype(np.float32),
+                           rng.normal(size=(120, 64)) * 4)),
+    ("heavy_tail", lambda rng: (rng.standard_cauchy(size=(200, 48)).astype(np.float32),
+                                rng.standard_cauchy(size=(60, 48)))),
+    ("tiny_and_huge_rows", lambda rng: (np.concatenate([rng.normal(size=(50, 32)) * 1e-6,
+                                                         rng.normal(size=(50, 32)) * 1e6]).astype(np.float32),
+                                        np.concatenate([rng.normal(size=(20, 32)) * 1e-6,
+                                                        rng.normal(size=(20, 32)) * 1e6]))),
+]
+
+
+@pytest.mark.parametrize("name", ["gauss", "blobs", "heavy_tail", "tiny_and_huge_rows"])
+def test_r_tilde_stays_inside_the_bound(name):
+    rng = np.random.default_rng(abs(hash(name)) % 2 ** 32)
+    X, W = dict((c[0], c[1]) for c in CASES)[name](rng)
+    X = np.asarray(X, dtype=np.float32).astype(np.float64)
+    W = np.asarray(W, dtype=np.float64)
+    rt, (sx, l1x, xx, tw, l1w, yy) = r_tilde(X, W)
+    r = exact_r(X, W)
+    eps = filter_eps(sx, l1x, xx, l1w.max(), tw.max(), yy.max(), X.shape[1])
+    err = np.abs(rt - r)
+    assert (err <= eps[:, None]).all(), float((err / eps[:, None]).max())
+    # the bound is not absurdly loose either (within ~3 orders of magnitude of the worst error)
+    assert (err / eps[:, None]).max() > 1e-4
+
+
+def test_spiky_rows_and_zero_rows():
+    rng = np.random.default_rng(3)
+    X = ((rng.random((150, 80)) < 0.05) * rng.normal(size=(150, 80)) * 100).astype(np.float32).astype(np.float64)
+    X[7] = 0.0
+    W = (rng.random((40, 80)) < 0.1) * rng.normal(size=(40, 80)) * 50
+    W[3] = 0.0
+    rt, (sx, l1x, xx, tw, l1w, yy) = r_tilde(X, W)
+    eps = filter_eps(sx, l1x, xx, l1w.max(), tw.max(), yy.max(), 80)
+    assert (np.abs(rt - exact_r(X, W)) <= eps[:, None]).all()
+
+
+def test_candidate_rule_keeps_every_possible_winner():
+    """For ANY seed: {j : r~_ij <= r~_i,seed + 2 eps_i} contains every j with r_ij <= r_i,seed,
+    hence the exact winner and all its ties."""
+    rng = np.random.default_rng(11)
+    X = rng.normal(size=(500, 40)).astype(np.float32).astype(np.float64)
+    W = rng.normal(size=(200, 40))
+    W[50:60] = W[40:50]                      # exact duplicates
+    W[60:70] = W[40:50] * (1 + 1e-12)        # near duplicates
+    rt, (sx, l1x, xx, tw, l1w, yy) = r_tilde(X, W)
+    r = exact_r(X, W)
+    eps = filter_eps(sx, l1x, xx, l1w.max(), tw.max(), yy.max(), 40)
+    for seeds in (r.argmin(1), rng.integers(0, 200, 500), np.zeros(500, int)):
+        thr = rt[np.arange(500), seeds] + 2 * eps
+        cand = rt <= thr[:, None]
+        must = r <= r[np.arange(500), seeds][:, None]
+        assert (cand | ~must).all()
+        assert cand[np.arange(500), r.argmin(1)].all()
+
+
+def test_coarse_prepass_is_a_valid_seed_source():
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(200, 64)).astype(np.float32).astype(np.float64)
+    W = rng.normal(size=(300, 64))
+    rt2, _ = r_tilde(X, W, levels=2)
+    seeds = rt2[:, ::4].argmin(1) * 4       # every 4th prototype, two digit levels
+    assert seeds.max() < 300
+    r = exact_r(X, W)
+    # coarse seeds are near-minimal: within a few coarse error units of the true minimum
+    gap = r[np.arange(200), seeds] - r.min(1)
+    assert np.median(gap) < np.median(np.sort(r, 1)[:, 8] - r.min(1))
