@@ -39,7 +39,7 @@ SIGNATURES = {
     "dbgsom_filter_prepare": (_ci, [_vp, _ci, _i64, _i64, _i64, _vp, _sz, _vp]),
     "dbgsom_bmu_filtered_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dbgsom_bmu_filtered": (_ci, [_vp, _ci, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
-                                  _ci, _ci, _vp, _vp, _vp, _sz, _vp]),
+                                  _ci, _ci, _ci, _vp, _vp, _vp, _sz, _vp]),
     "dbgsom_bmu_filtered_counts": (_ci, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "dbgsom_filter_timing": (_ci, [_ci]),
     "dbgsom_bmu_filtered_stage_ms": (_ci, [_vp]),

@@ -195,6 +195,9 @@ class HipBackend(HotPathBackend):
     # the stateless seed pre-pass looks at every seed_stride-th prototype (results do not depend
     # on it; 4 balances the pre-pass against longer candidate lists at the bench shapes)
     seed_stride = 4
+    # digit planes of the candidate sweep: 2 = three int8 digit products, 3 = six (tighter bound,
+    # twice the MFMA work); results do not depend on it
+    sweep_planes = int(os.environ.get("DBGSOM_SWEEP_PLANES", "2"))
 
     def __init__(self, device: Optional[int] = None, algorithm: str = "auto"):
         """algorithm (all give IDENTICAL results):
@@ -353,7 +356,8 @@ class HipBackend(HotPathBackend):
         prev_p, order_p = self._hint()
         self._timed_call("bmu", "dbgsom_bmu_filtered", self._p(self._X), _native.F32, N, d, d,
                          self._p(self._xx), self._p(self._planes), self._p(Wd), M, self._p(wwd),
-                         prev_p, order_p, int(self.seed_stride), round_f32, self._p(idx),
+                         prev_p, order_p, int(self.seed_stride), int(self.sweep_planes), round_f32,
+                         self._p(idx),
                          self._p(dist), self._p(ws), ws.numel(), self._stream())
         return dist, idx
 

@@ -118,10 +118,13 @@ __global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict_
 //   eps = 2 (quantisation + dropped) + rounding.
 // A prototype j with r_chain(i, j) <= r_chain(i, prev) has r~_j <= r~_prev + 2 eps: the test the
 // sweep applies.
+// With two digit planes (products a + b <= 1) the dropped set also holds the three level-2
+// products: d * 128 * 128 * (3 * 65536 + 2 * 256 + 1) * s t / F^2.
 __device__ __forceinline__ double filter_eps(double s, double l1x, double xx, double l1w_max,
-                                             double t_max, double yy_max, int d) {
+                                             double t_max, double yy_max, int d, int planes) {
     const double quant = (s * l1w_max + t_max * l1x) / (2.0 * FQ) + (double)d * s * t_max / (4.0 * FQ * FQ);
-    const double dropped = (double)d * (16384.0 * 513.0) * s * t_max / (FQ * FQ);
+    const double per_k = 16384.0 * (planes >= 3 ? 513.0 : (3.0 * 65536.0 + 513.0));
+    const double dropped = (double)d * per_k * s * t_max / (FQ * FQ);
     const double rounding = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xx + yy_max);
     return 2.0 * (quant + dropped) * (1.0 + 1e-7) + rounding;
 }
@@ -152,7 +155,7 @@ constexpr int SW_SMEM = SW_OFF_MASK + (SW_MAX_M + 31) / 32 * 4 + 64;
 //   digit products with a + b <= 1 (two planes per operand), natural sample order
 //   (order == nullptr), output seed[i] = arg-min of that coarser r~ -- any index is a valid
 //   starting point for MODE 0, a near-minimal one keeps its candidate lists short.
-template <int MODE>
+template <int MODE, int PLANES>
 __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx,
     const double *__restrict__ l1x, const double *__restrict__ xx, int64_t N, int d, int dpad,
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     int64_t *__restrict__ seed, int jstride, int w_rows) {
     // jstride (MODE 1 only): the pre-pass looks at every jstride-th prototype; M is then the
     // number of those and `ww` / `ctab` are the strided tables
-    constexpr int NPL = (MODE == 0) ? 3 : 2;       // digit planes used per operand
-    constexpr int NLV = (MODE == 0) ? 3 : 2;       // accumulator levels
+    constexpr int NPL = PLANES;                    // digit planes used per operand (2 or 3)
+    constexpr int NLV = PLANES;                    // accumulator levels: products with a + b < PLANES
     constexpr int DMA_TILE = 2 * NPL;              // DMA instructions per wave per tile
     __shared__ __attribute__((aligned(16))) char smem[SW_SMEM];
     double *thr_s = reinterpret_cast<double *>(smem + SW_OFF_THR);
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         s_i[it] = sx[i];
         xx_i[it] = xx[i];
         if constexpr (MODE == 0) {
-            eps2_i[it] = 2.0 * filter_eps(s_i[it], l1x[i], xx_i[it], l1w_max, t_max, yy_max, d);
+            eps2_i[it] = 2.0 * filter_eps(s_i[it], l1x[i], xx_i[it], l1w_max, t_max, yy_max, d, PLANES);
             prev_i[it] = prev_s[il];
             thr_i[it] = thr_s[il];
         } else {
@@ -311,9 +314,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     acc[it][L] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[pw], xf[it][px], acc[it][L], 0, 0, 0)
             DBGSOM_I8(0, 0, 0, 0); DBGSOM_I8(1, 0, 0, 0);
             DBGSOM_I8(0, 0, 1, 1); DBGSOM_I8(1, 0, 1, 1);
-            if constexpr (MODE == 0) { DBGSOM_I8(0, 0, 2, 2); DBGSOM_I8(1, 0, 2, 2); }
+            if constexpr (PLANES == 3) { DBGSOM_I8(0, 0, 2, 2); DBGSOM_I8(1, 0, 2, 2); }
             DBGSOM_I8(0, 1, 0, 1); DBGSOM_I8(1, 1, 0, 1);
-            if constexpr (MODE == 0) {
+            if constexpr (PLANES == 3) {
                 DBGSOM_I8(0, 1, 1, 2); DBGSOM_I8(1, 1, 1, 2);
                 DBGSOM_I8(0, 2, 0, 2); DBGSOM_I8(1, 2, 0, 2);
             }
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int jl = wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     double T = (double)acc[it][0][r] * 256.0 + (double)acc[it][1][r];
-                    if constexpr (MODE == 0) T = T * 256.0 + (double)acc[it][2][r];
+                    if constexpr (PLANES == 3) T = T * 256.0 + (double)acc[it][2][r];
                     else T = T * 256.0;
                     rv[it][r] = (xx_i[it] + ytab[jl]) - s_i[it] * (ctb[jl] * T);
                 }
@@ -701,10 +704,12 @@ size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M) {
 int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                         const double *xx_dev, const void *xplanes_dev, const double *W_dev,
                         int64_t M, const double *ww_dev, const int64_t *prev_idx_dev,
-                        const int32_t *order_dev, int seed_stride, int round_f32,
-                        int64_t *idx_dev, double *dist_dev, void *workspace_dev,
+                        const int32_t *order_dev, int seed_stride, int sweep_planes,
+                        int round_f32, int64_t *idx_dev, double *dist_dev, void *workspace_dev,
                         size_t workspace_bytes, void *stream) {
     DBGSOM_REQUIRE(seed_stride >= 0 && seed_stride <= 64, "seed_stride outside [0, 64]");
+    DBGSOM_REQUIRE(sweep_planes == 0 || sweep_planes == 2 || sweep_planes == 3, "sweep_planes must be 0, 2 or 3");
+    if (sweep_planes == 0) sweep_planes = 2;
     DBGSOM_REQUIRE(x_dtype == DBGSOM_F32, "the filtered search takes float32 samples");
     DBGSOM_REQUIRE(N >= 1 && N < 0x7fffffff && d >= 1 && d % KT == 0 && ldx >= d, "bad sample shape (d must be a multiple of 16)");
     DBGSOM_REQUIRE(M >= 1 && M <= SW_MAX_M, "M outside [1, 16000]");
@@ -737,7 +742,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     g_timer.mark(1, s);
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
-        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
+        hipLaunchKernelGGL((sweep_i8_kernel<1, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yy_sub, f.ctab_sub,
                            f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
                            f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, (int)M);
@@ -750,10 +755,16 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         g_timer.mark(2, s);
     }
     g_timer.mark(3, s);
-    hipLaunchKernelGGL(sweep_i8_kernel<0>, dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes, xb.scale,
-                       xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab, f.summary, (int)M,
-                       prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount, (int64_t *)nullptr, 1,
-                       (int)M);
+    if (sweep_planes == 3)
+        hipLaunchKernelGGL((sweep_i8_kernel<0, 3>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
+                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab,
+                           f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
+                           (int64_t *)nullptr, 1, (int)M);
+    else
+        hipLaunchKernelGGL((sweep_i8_kernel<0, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
+                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab,
+                           f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
+                           (int64_t *)nullptr, 1, (int)M);
     g_timer.mark(4, s);
     hipLaunchKernelGGL(subset_exact_kernel, dim3((unsigned)f.nb), dim3(NT), 0, s,
                        (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev,

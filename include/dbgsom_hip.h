@@ -124,7 +124,10 @@ int dbgsom_smooth(const double *sums_dev, int64_t M, int64_t d, const float *hop
  *                 products, every seed_stride-th prototype; 0 = default 4) finds a starting
  *                 prototype per sample and the samples are bucketed by it; nothing from an earlier
  *                 call is used.  The seed only sets the candidate threshold: ANY seed gives the
- *                 exact result, a nearer one shorter candidate lists. */
+ *                 exact result, a nearer one shorter candidate lists.
+ *   sweep_planes: digit planes per operand in the candidate sweep: 3 = six digit products (error
+ *                 bound ~1e-6 of |x||w|), 2 = three products (bound ~3e-4, half the MFMA work and
+ *                 two thirds of the traffic, somewhat longer candidate lists); 0 = default (2). */
 size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d);
 int dbgsom_filter_prepare(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                           void *planes_dev, size_t planes_bytes, void *stream);
@@ -132,8 +135,8 @@ size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M);
 int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                         const double *xx_dev, const void *xplanes_dev, const double *W_dev,
                         int64_t M, const double *ww_dev, const int64_t *prev_idx_dev,
-                        const int32_t *order_dev, int seed_stride, int round_f32,
-                        int64_t *idx_dev, double *dist_dev, void *workspace_dev,
+                        const int32_t *order_dev, int seed_stride, int sweep_planes,
+                        int round_f32, int64_t *idx_dev, double *dist_dev, void *workspace_dev,
                         size_t workspace_bytes, void *stream);
 /* diagnostics: per-stage HIP-event timing of dbgsom_bmu_filtered on the caller's stream.
  * ms5 = [slice W + tables, coarse pre-pass, bucket sort, int8 sweep, exact search on candidates] */

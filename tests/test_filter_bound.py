@@ -36,9 +36,10 @@ def r_tilde(X, W, levels=3):
         (sx, l1x, xx, tw, l1w, yy)
 
 
-def filter_eps(s, l1x, xx, l1w_max, t_max, yy_max, d):
+def filter_eps(s, l1x, xx, l1w_max, t_max, yy_max, d, planes=3):
     quant = (s * l1w_max + t_max * l1x) / (2.0 * F) + d * s * t_max / (4.0 * F * F)
-    dropped = d * (16384.0 * 513.0) * s * t_max / (F * F)
+    per_k = 16384.0 * (513.0 if planes >= 3 else 3.0 * 65536.0 + 513.0)
+    dropped = d * per_k * s * t_max / (F * F)
     rounding = 4.0 * (d + 16) * 1.1102230246251565e-16 * (xx + yy_max)
     return 2.0 * (quant + dropped) * (1.0 + 1e-7) + rounding
 
@@ -68,13 +69,14 @@ def test_r_tilde_stays_inside_the_bound(name):
     X, W = dict((c[0], c[1]) for c in CASES)[name](rng)
     X = np.asarray(X, dtype=np.float32).astype(np.float64)
     W = np.asarray(W, dtype=np.float64)
-    rt, (sx, l1x, xx, tw, l1w, yy) = r_tilde(X, W)
     r = exact_r(X, W)
-    eps = filter_eps(sx, l1x, xx, l1w.max(), tw.max(), yy.max(), X.shape[1])
-    err = np.abs(rt - r)
-    assert (err <= eps[:, None]).all(), float((err / eps[:, None]).max())
-    # the bound is not absurdly loose either (within ~3 orders of magnitude of the worst error)
-    assert (err / eps[:, None]).max() > 1e-4
+    for planes in (3, 2):
+        rt, (sx, l1x, xx, tw, l1w, yy) = r_tilde(X, W, levels=planes)
+        eps = filter_eps(sx, l1x, xx, l1w.max(), tw.max(), yy.max(), X.shape[1], planes)
+        err = np.abs(rt - r)
+        assert (err <= eps[:, None]).all(), (planes, float((err / eps[:, None]).max()))
+        # the bound is not absurdly loose either (within ~3-4 orders of magnitude of the worst error)
+        assert (err / eps[:, None]).max() > 1e-5
 
 
 def test_spiky_rows_and_zero_rows():
