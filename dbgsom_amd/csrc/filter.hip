@@ -139,23 +139,35 @@ __device__ __forceinline__ void fdma16(const void *src, void *lds_dst) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_dst, 16, 0, 0);
 }
 
-constexpr int SW_PLANE = 128 * FKT;                 // 8 KB: one plane of one operand per stage
-constexpr int SW_STAGE = 6 * SW_PLANE;              // X planes 0..2, W planes 0..2
-constexpr int SW_TAB = 128 * 8;                     // one table (128 doubles)
-constexpr int SW_OFF_TAB = FSTAGES * SW_STAGE;      // 3 x (yy | ctab)
-constexpr int SW_OFF_THR = SW_OFF_TAB + 3 * 2 * SW_TAB;
-constexpr int SW_OFF_PREV = SW_OFF_THR + 128 * 8;
-constexpr int SW_OFF_MASK = SW_OFF_PREV + 128 * 4;
+constexpr int SW_PLANE = 128 * FKT;  // 8 KB: 128 rows of one digit plane per stage
 constexpr int SW_MAX_M = 16000;
-constexpr int SW_SMEM = SW_OFF_MASK + (SW_MAX_M + 31) / 32 * 4 + 64;
 
-// MODE 0 (mark): the sweep described above -- six digit products, samples in bucket order of
-//   `prev`, candidate prototypes of every 128-sample workgroup written to ulist / ucount.
-// MODE 1 (seed): a cheaper pre-pass when there is no previous winner to start from: the three
-//   digit products with a + b <= 1 (two planes per operand), natural sample order
-//   (order == nullptr), output seed[i] = arg-min of that coarser r~ -- any index is a valid
-//   starting point for MODE 0, a near-minimal one keeps its candidate lists short.
-template <int MODE, int PLANES>
+// LDS map of one sweep instantiation: 3 ring stages of NPL X planes (128 rows) + NPL W planes
+// (128 JT rows), then 3 x (|w|^2 | ctab) chunk tables, the thresholds, the seeds and the bitmask
+template <int PLANES, int JT>
+struct SweepLds {
+    static constexpr int BJ = 128 * JT;                         // prototypes per chunk
+    static constexpr int W_PLANE = SW_PLANE * JT;
+    static constexpr int STAGE = PLANES * (SW_PLANE + W_PLANE);  // 48 KB for (3,1) and (2,2)
+    static constexpr int TAB = BJ * 8;
+    static constexpr int OFF_TAB = FSTAGES * STAGE;
+    static constexpr int OFF_THR = OFF_TAB + 3 * 2 * TAB;
+    static constexpr int OFF_PREV = OFF_THR + 128 * 8;
+    static constexpr int OFF_MASK = OFF_PREV + 128 * 4;
+    static constexpr int OFF_MISC = OFF_MASK + (SW_MAX_M + 31) / 32 * 4;
+    static constexpr int BYTES = OFF_MISC + 16;
+};
+
+// MODE 0 (mark): the candidate sweep described above; samples in bucket order of `prev`,
+//   candidate prototypes of every 128-sample workgroup written to ulist / ucount.
+// MODE 1 (seed): the pre-pass when there is no previous winner to start from: natural sample
+//   order (order == nullptr), every jstride-th prototype (M = their number, ww / ctab = strided
+//   tables), output seed[i] = arg-min of r~ -- any index is a valid starting point for MODE 0, a
+//   near-minimal one keeps its candidate lists short.
+// PLANES = digit planes per operand: 3 -> six digit products (a + b <= 2), 2 -> three (a + b <= 1).
+// JT = 32-prototype tiles per wavefront: workgroup tile = 128 samples x 128 JT prototypes
+//   (8 wavefronts as 2 x 4, each 64 x 32 JT); JT = 2 halves the number of passes over the X planes.
+template <int MODE, int PLANES, int JT>
 __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx,
     const double *__restrict__ l1x, const double *__restrict__ xx, int64_t N, int d, int dpad,
@@ -164,21 +176,19 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount,
     int64_t *__restrict__ seed, int jstride, int w_rows) {
-    // jstride (MODE 1 only): the pre-pass looks at every jstride-th prototype; M is then the
-    // number of those and `ww` / `ctab` are the strided tables
-    constexpr int NPL = PLANES;                    // digit planes used per operand (2 or 3)
-    constexpr int NLV = PLANES;                    // accumulator levels: products with a + b < PLANES
-    constexpr int DMA_TILE = 2 * NPL;              // DMA instructions per wave per tile
-    __shared__ __attribute__((aligned(16))) char smem[SW_SMEM];
-    double *thr_s = reinterpret_cast<double *>(smem + SW_OFF_THR);
-    int *prev_s = reinterpret_cast<int *>(smem + SW_OFF_PREV);
-    uint32_t *mask = reinterpret_cast<uint32_t *>(smem + SW_OFF_MASK);
-    int *misc = reinterpret_cast<int *>(smem + SW_OFF_MASK + (SW_MAX_M + 31) / 32 * 4);
+    using L = SweepLds<PLANES, JT>;
+    constexpr int NPL = PLANES, NLV = PLANES, BJ = L::BJ;
+    constexpr int DMA_TILE = NPL * (1 + JT);  // DMA instructions per wave per tile
+    __shared__ __attribute__((aligned(16))) char smem[L::BYTES];
+    double *thr_s = reinterpret_cast<double *>(smem + L::OFF_THR);
+    int *prev_s = reinterpret_cast<int *>(smem + L::OFF_PREV);
+    uint32_t *mask = reinterpret_cast<uint32_t *>(smem + L::OFF_MASK);
+    int *misc = reinterpret_cast<int *>(smem + L::OFF_MISC);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave >> 2, wj = wave & 3;  // 2 (samples) x 4 (prototypes) wavefronts, 64 x 32 each
+    const int wi = wave >> 2, wj = wave & 3;  // 2 (samples) x 4 (prototypes) wavefronts
     const int lc = lane & 31, lh = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * 128;  // first sorted position of this workgroup
     const int nwords = (M + 31) / 32;
@@ -228,10 +238,10 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             eps2_i[it] = 0.0; prev_i[it] = -1; thr_i[it] = 0.0;
         }
     }
-    double bestv[2] = {INFINITY, INFINITY};  // MODE 1: running arg-min of the coarse r~
+    double bestv[2] = {INFINITY, INFINITY};  // MODE 1: running arg-min of r~
     int bestj[2] = {0, 0};
 
-    // ---- DMA sources: wave w loads, per plane, X rows 16w..16w+15 and W rows 16w..16w+15 -------
+    // ---- DMA sources: per plane, wave w loads X rows 16w..16w+15 and W rows 16w + 128u ..+15 ----
     const int dr = 16 * wave + (lane >> 2), dcp = lane & 3;
     const int dc = dcp ^ ((dr >> 2) & 3);  // source chunk for the linear LDS chunk (swizzle)
     const int64_t xpos = (p0 + dr < N) ? (p0 + dr) : (N - 1);
@@ -239,50 +249,60 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const size_t wplane_stride = (size_t)w_rows * dpad;  // rows of one W plane (all prototypes)
     const int8_t *xsrc = xplanes + (size_t)sample_at(xpos) * dpad + dc * 16;
     const int nkt = dpad / FKT;
-    const int nchunk = (M + 127) / 128;
+    const int nchunk = (M + BJ - 1) / BJ;
     const int ntile = nkt * nchunk;
-    const int c0 = jlo / 128;  // the sweep starts at the chunk holding the previous winners
+    const int c0 = jlo / BJ;  // the sweep starts at the chunk holding the seeds
 
     auto chunk_of = [&](int t) { int c = c0 + t / nkt; return c >= nchunk ? c - nchunk : c; };
     auto issue = [&](int t) {
-        const int c_t = chunk_of(t), k0 = (t % nkt) * FKT, jc_t = c_t * 128;
-        char *stage = smem + (t % FSTAGES) * SW_STAGE;
-        int jw = jc_t + dr;
-        jw = jw < M ? jw : M - 1;
-        if constexpr (MODE == 1) jw *= jstride;
-        const int8_t *wsrc = wplanes + (size_t)jw * dpad + dc * 16 + k0;
+        const int c_t = chunk_of(t), k0 = (t % nkt) * FKT, jc_t = c_t * BJ;
+        char *stage = smem + (t % FSTAGES) * L::STAGE;
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) {
+        for (int p = 0; p < NPL; ++p)
             fdma16(xsrc + p * xplane_stride + k0, stage + p * SW_PLANE + 1024 * wave);
-            fdma16(wsrc + p * wplane_stride, stage + (3 + p) * SW_PLANE + 1024 * wave);
+#pragma unroll
+        for (int u = 0; u < JT; ++u) {
+            int jw = jc_t + 128 * u + dr;
+            jw = jw < M ? jw : M - 1;
+            if constexpr (MODE == 1) jw *= jstride;
+            const int8_t *wsrc = wplanes + (size_t)jw * dpad + dc * 16 + k0;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+                fdma16(wsrc + p * wplane_stride,
+                       stage + NPL * SW_PLANE + p * L::W_PLANE + 8192 * u + 1024 * wave);
         }
-        if (t % nkt == 0) {  // this chunk's tables: even waves |w|^2, odd waves ctab (identical copies)
-            const int j2 = jc_t + 2 * lane;  // both tables are padded to a multiple of 128 entries
-            char *tab = smem + SW_OFF_TAB + ((t / nkt) % 3) * 2 * SW_TAB;
-            if (wave & 1) fdma16(ctab + j2, tab + SW_TAB);
-            else fdma16(ww + j2, tab);
+        if (t % nkt == 0) {  // this chunk's tables (1 KB pieces; the 8 waves cover them, twice for JT = 1)
+            constexpr int PIECES = 2 * JT;  // |w|^2 pieces, then ctab pieces
+            const int piece = wave % PIECES, half = piece % JT;
+            const int j2 = jc_t + 128 * half + 2 * lane;  // tables are padded to a multiple of 256 entries
+            char *tab = smem + L::OFF_TAB + ((t / nkt) % 3) * 2 * L::TAB;
+            if (piece >= JT) fdma16(ctab + j2, tab + L::TAB + 1024 * half);
+            else fdma16(ww + j2, tab + 1024 * half);
         }
     };
 
-    // fragment read offsets inside a stage
-    int xoff[2], woff;
+    // fragment read offsets inside a stage (bytes); chunk (2 ks + lh) ^ swz = (2 ks) ^ (lh ^ swz):
+    // k-step 1 flips byte 32
+    int xoff[2], woff[JT];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int r = wi * 64 + it * 32 + lc;
         xoff[it] = r * FKT + ((lh ^ ((r >> 2) & 3)) * 16);
     }
-    {
-        const int r = wj * 32 + lc;
-        woff = 3 * SW_PLANE + r * FKT + ((lh ^ ((r >> 2) & 3)) * 16);
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        const int r = wj * 32 * JT + jt * 32 + lc;
+        woff[jt] = NPL * SW_PLANE + r * FKT + ((lh ^ ((r >> 2) & 3)) * 16);
     }
-    // chunk (2 ks + lh) ^ swz = (2 ks) ^ (lh ^ swz): k-step 1 flips bit 1 of the chunk -> byte 32
-    v16i_t acc[2][NLV];
+    v16i_t acc[JT][2][NLV];
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-        for (int L = 0; L < NLV; ++L)
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[it][L][r] = 0;
+            for (int lv = 0; lv < NLV; ++lv)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jt][it][lv][r] = 0;
 
     issue(0);
     if (ntile > 1) issue(1);
@@ -298,89 +318,91 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         asm volatile("" ::: "memory");
         if (t + 2 < ntile) issue(t + 2);
 
-        const char *stage = smem + (t % FSTAGES) * SW_STAGE;
+        const char *stage = smem + (t % FSTAGES) * L::STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            v4i_t xf[2][NPL], wf[NPL];
+            v4i_t xf[2][NPL], wf[JT][NPL];
 #pragma unroll
             for (int p = 0; p < NPL; ++p) {
-                wf[p] = *reinterpret_cast<const v4i_t *>(stage + p * SW_PLANE + (woff ^ (ks * 32)));
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    wf[jt][p] = *reinterpret_cast<const v4i_t *>(stage + p * L::W_PLANE + (woff[jt] ^ (ks * 32)));
 #pragma unroll
                 for (int it = 0; it < 2; ++it)
                     xf[it][p] = *reinterpret_cast<const v4i_t *>(stage + p * SW_PLANE + (xoff[it] ^ (ks * 32)));
             }
-            // six digit products, level = plane(x) + plane(w); prototypes = rows (A), samples = cols (B)
-#define DBGSOM_I8(it, px, pw, L) \
-    acc[it][L] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[pw], xf[it][px], acc[it][L], 0, 0, 0)
-            DBGSOM_I8(0, 0, 0, 0); DBGSOM_I8(1, 0, 0, 0);
-            DBGSOM_I8(0, 0, 1, 1); DBGSOM_I8(1, 0, 1, 1);
-            if constexpr (PLANES == 3) { DBGSOM_I8(0, 0, 2, 2); DBGSOM_I8(1, 0, 2, 2); }
-            DBGSOM_I8(0, 1, 0, 1); DBGSOM_I8(1, 1, 0, 1);
-            if constexpr (PLANES == 3) {
-                DBGSOM_I8(0, 1, 1, 2); DBGSOM_I8(1, 1, 1, 2);
-                DBGSOM_I8(0, 2, 0, 2); DBGSOM_I8(1, 2, 0, 2);
-            }
-#undef DBGSOM_I8
+            // digit products, level = plane(x) + plane(w); prototypes = rows (A), samples = cols (B)
+#pragma unroll
+            for (int lv = 0; lv < NLV; ++lv)
+#pragma unroll
+                for (int px = 0; px <= lv; ++px)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int it = 0; it < 2; ++it)
+                            acc[jt][it][lv] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                                wf[jt][lv - px], xf[it][px], acc[jt][it][lv], 0, 0, 0);
         }
 
         if (t % nkt == nkt - 1) {
-            const int c_t = chunk_of(t), jc = c_t * 128;
-            const double *ytab = reinterpret_cast<const double *>(smem + SW_OFF_TAB + ((t / nkt) % 3) * 2 * SW_TAB);
-            const double *ctb = ytab + 128;
-            const bool has_prev = (jc <= jhi) && (jc + 127 >= jlo);
+            const int c_t = chunk_of(t), jc = c_t * BJ;
+            const double *ytab = reinterpret_cast<const double *>(smem + L::OFF_TAB + ((t / nkt) % 3) * 2 * L::TAB);
+            const double *ctb = ytab + BJ;
+            const bool has_prev = (jc <= jhi) && (jc + BJ - 1 >= jlo);
             (void)has_prev;
-            // r~ of the lane's 2 x 16 pairs
-            double rv[2][16];
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int jl = wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    double T = (double)acc[it][0][r] * 256.0 + (double)acc[it][1][r];
-                    if constexpr (PLANES == 3) T = T * 256.0 + (double)acc[it][2][r];
-                    else T = T * 256.0;
-                    rv[it][r] = (xx_i[it] + ytab[jl]) - s_i[it] * (ctb[jl] * T);
-                }
             if constexpr (MODE == 0) {
-                if (has_prev) {  // bound from the starting prototype: thr_i = r~(i, prev_i) + 2 eps_i
+                if (has_prev) {  // bound from the seed: thr_i = r~(i, seed_i) + 2 eps_i
 #pragma unroll
-                    for (int it = 0; it < 2; ++it)
+                    for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int j = jc + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            if (j == prev_i[it]) thr_s[wi * 64 + it * 32 + lc] = rv[it][r] + eps2_i[it];
-                        }
+                        for (int it = 0; it < 2; ++it)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int jl = wj * 32 * JT + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                if (jc + jl == prev_i[it]) {
+                                    double T = (double)acc[jt][it][0][r] * 256.0 + (double)acc[jt][it][1][r];
+                                    if constexpr (PLANES == 3) T = T * 256.0 + (double)acc[jt][it][2][r];
+                                    else T = T * 256.0;
+                                    thr_s[wi * 64 + it * 32 + lc] =
+                                        ((xx_i[it] + ytab[jl]) - s_i[it] * (ctb[jl] * T)) + eps2_i[it];
+                                }
+                            }
                     __syncthreads();
 #pragma unroll
                     for (int it = 0; it < 2; ++it) thr_i[it] = thr_s[wi * 64 + it * 32 + lc];
                 }
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int j = jc + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (j < M && rv[it][r] <= thr_i[it]) atomicOr(&mask[j >> 5], 1u << (j & 31));
-                    }
-            } else {
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int j = jc + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (j < M && rv[it][r] < bestv[it]) { bestv[it] = rv[it][r]; bestj[it] = j * jstride; }
-                    }
             }
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
+            for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                for (int L = 0; L < NLV; ++L)
+                for (int it = 0; it < 2; ++it)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[it][L][r] = 0;
+                    for (int r = 0; r < 16; ++r) {
+                        const int jl = wj * 32 * JT + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int j = jc + jl;
+                        double T = (double)acc[jt][it][0][r] * 256.0 + (double)acc[jt][it][1][r];
+                        if constexpr (PLANES == 3) T = T * 256.0 + (double)acc[jt][it][2][r];
+                        else T = T * 256.0;
+                        const double rv = (xx_i[it] + ytab[jl]) - s_i[it] * (ctb[jl] * T);
+                        if constexpr (MODE == 0) {
+                            if (j < M && rv <= thr_i[it]) atomicOr(&mask[j >> 5], 1u << (j & 31));
+                        } else {
+                            if (j < M && rv < bestv[it]) { bestv[it] = rv; bestj[it] = j * jstride; }
+                        }
+                    }
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int lv = 0; lv < NLV; ++lv)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[jt][it][lv][r] = 0;
         }
     }
 
     if constexpr (MODE == 1) {
-        // seed = arg-min of the coarse r~ over the 2 lane halves and the 4 prototype wavefronts
+        // seed = arg-min of r~ over the 2 lane halves and the 4 prototype wavefronts
         __syncthreads();
         double *sv = reinterpret_cast<double *>(smem);          // [4][128]
         int *sj = reinterpret_cast<int *>(smem + 4 * 128 * 8);  // [4][128]
@@ -607,7 +629,7 @@ struct FilterWs {
     int64_t nb, Mpad;
 };
 static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_t M) {
-    const int64_t Mpad = (M + 127) / 128 * 128, nb = (N + 127) / 128;
+    const int64_t Mpad = (M + 255) / 256 * 256, nb = (N + 127) / 128;
     size_t off = carve_planes(f ? &f->w : nullptr, base, M, d);
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o0 = take((size_t)Mpad * 8), o1 = take((size_t)Mpad * 8), o2 = take(64);
@@ -742,7 +764,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     g_timer.mark(1, s);
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
-        hipLaunchKernelGGL((sweep_i8_kernel<1, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
+        hipLaunchKernelGGL((sweep_i8_kernel<1, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yy_sub, f.ctab_sub,
                            f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
                            f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, (int)M);
@@ -756,12 +778,12 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     }
     g_timer.mark(3, s);
     if (sweep_planes == 3)
-        hipLaunchKernelGGL((sweep_i8_kernel<0, 3>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
+        hipLaunchKernelGGL((sweep_i8_kernel<0, 3, 1>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab,
                            f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
                            (int64_t *)nullptr, 1, (int)M);
     else
-        hipLaunchKernelGGL((sweep_i8_kernel<0, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
+        hipLaunchKernelGGL((sweep_i8_kernel<0, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab,
                            f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
                            (int64_t *)nullptr, 1, (int)M);
