@@ -42,9 +42,12 @@ WORKLOADS = {
 }
 F64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 cycles (v_mfma_f64_16x16x4_f64)
 I8_MFMA_PEAK_TOPS = 5033.0   # 256 x 4 x 2.4 GHz x 65536 op / 32 cycles (v_mfma_i32_32x32x32_i8, dense)
-# HBM-side bytes of one sweep_i8_kernel<0> launch at C4 from the PMC pass committed under
-# profiles/ (FETCH_SIZE x 2 per the gfx950 correction); not measurable inside this process
-SWEEP_TRAFFIC_C4_BYTES = 2.42e10
+# HBM-side bytes of one full-sweep launch at C4 from the PMC passes committed under profiles/
+# (FETCH_SIZE x 2 per the gfx950 correction); not measurable inside this process.  Keyed by the
+# number of digit planes the sweep reads (2 -> sweep_i8_kernel<0,2,2>, 3 -> sweep_i8_kernel<0,3,1>)
+SWEEP_TRAFFIC_C4_BYTES = {2: 7.93e9, 3: 2.42e10}
+SWEEP_KERNEL = {2: "sweep_i8_kernel<0,2,2>", 3: "sweep_i8_kernel<0,3,1>"}
+SWEEP_PRODUCTS = {2: 3, 3: 6}   # int8 digit products kept per (sample, prototype, k)
 
 
 def lattice_hops(rows, cols):
@@ -300,14 +303,16 @@ def main():
             roof = exact_roof
         else:
             dpad = (d + 63) // 64 * 64
-            ops = 2.0 * n_gpu * M * dpad * 6  # six int8 digit products per (sample, prototype, k)
+            from dbgsom_amd.backend import HipBackend as _HB
+            planes = int(_HB.sweep_planes)
+            ops = 2.0 * n_gpu * M * dpad * SWEEP_PRODUCTS[planes]  # int8 ops the sweep executes
             ach = ops / (stage["sweep"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "sweep_i8_kernel<0>", "dtype": "i8",
+            roof = {"bound": "mfma", "kernel": SWEEP_KERNEL[planes], "dtype": "i8",
                     "achieved": ach, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                     "frac": ach / I8_MFMA_PEAK_TOPS,
-                    "traffic": SWEEP_TRAFFIC_C4_BYTES if args.workload == "c4" and
+                    "traffic": SWEEP_TRAFFIC_C4_BYTES[planes] if args.workload == "c4" and
                     n_gpu == WORKLOADS["c4"][0] else None,
-                    "kernel_ms": stage["sweep"],
+                    "kernel_ms": stage["sweep"], "digit_products": SWEEP_PRODUCTS[planes],
                     "algorithmic_equiv_TFLOPs": flops / (stage["sweep"] * 1e-3) / 1e12}
         out = {
             "metric": "samples/sec/epoch (BMU+update)",

@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libdbgsom_hip.so")
+# DBGSOM_LIB: load another build of the same ABI (kernel experiments); default = the in-tree build
+LIB_PATH = os.environ.get("DBGSOM_LIB") or os.path.join(CSRC, "libdbgsom_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "dbgsom_hip.h")
 
 F32, F64, BF16 = 0, 1, 2

@@ -30,8 +30,17 @@ constexpr double FQ = 8323072.0;  // 127 * 2^16
 constexpr int FKT = 64;           // bytes (= features) per plane row per LDS stage
 constexpr int FNT = 512;          // threads per sweep workgroup (8 wavefronts)
 constexpr int FSTAGES = 3;
+#ifndef SWEEP_EXPERIMENT
+#define SWEEP_EXPERIMENT 0  // timing experiments only: 1 no X DMA, 2 no W DMA, 4 no MFMA, 8 no chunk epilogue,
+// 32 contiguous X source addressing, 64 (with 8) products dead
+#endif
 
-inline int64_t filter_dpad(int64_t d) { return (d + FKT - 1) / FKT * FKT; }
+// plane rows are padded to whole k-tiles, at least two of them (the sweep's ring runs three tiles
+// ahead and keeps three chunk tables)
+inline int64_t filter_dpad(int64_t d) {
+    const int64_t p = (d + FKT - 1) / FKT * FKT;
+    return p < 2 * FKT ? 2 * FKT : p;
+}
 
 // ---- 1. digit planes --------------------------------------------------------------------------
 // planes: int8 [3][rows][dpad]; scale[rows] = s; l1[rows] = sum |a_k|
@@ -69,6 +78,58 @@ __global__ __launch_bounds__(256) void slice_rows_kernel(const T *__restrict__ A
         p0[k] = (int8_t)d0;
         p0[plane_stride + k] = (int8_t)d1;
         p0[2 * plane_stride + k] = (int8_t)d2;
+    }
+}
+
+// The prototypes' digit planes in the order the sweep's DMA wants them: int8 [3][dpad / 64][rows_pad]
+// [64], i.e. k-tile-major, so that the 64-byte pieces of 16 consecutive rows are ONE contiguous
+// KiB (whole 128-byte lines per DMA instruction instead of 16 half lines), with the 16-byte
+// chunks of a piece already XOR-swizzled by (row >> 2) & 3 the way the LDS image is read.
+// wt: all M prototypes (rows_pad = Mpad); wt_sub: every `stride`-th (rows_pad = Msubpad), the
+// seed pre-pass.  Pad rows are never initialised: the sweep masks j >= M.
+__global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__restrict__ W, int M, int d,
+                                                            int dpad, int Mpad, int stride,
+                                                            int Msubpad, int8_t *__restrict__ wt,
+                                                            int8_t *__restrict__ wt_sub,
+                                                            double *__restrict__ scale,
+                                                            double *__restrict__ l1) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const double *a = W + (size_t)row * d;
+    double m = 0.0, s1 = 0.0;
+    for (int k = lane; k < d; k += 64) {
+        const double v = fabs(a[k]);
+        m = fmax(m, v);
+        s1 += v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmax(m, __shfl_xor(m, off, 64));
+        s1 += __shfl_xor(s1, off, 64);
+    }
+    const double s = (m > 0.0) ? m : 1.0;
+    if (lane == 0) { scale[row] = s; l1[row] = s1; }
+    const size_t plane_stride = (size_t)Mpad * dpad, sub_stride = (size_t)Msubpad * dpad;
+    const bool in_sub = (row % stride) == 0;
+    const int q = row / stride;
+    for (int k = lane; k < dpad; k += 64) {
+        int v = 0;
+        if (k < d) v = (int)rint(a[k] / s * FQ);
+        const int d2 = ((v + 128) & 255) - 128;
+        const int v1 = (v - d2) >> 8;
+        const int d1 = ((v1 + 128) & 255) - 128;
+        const int d0 = (v1 - d1) >> 8;
+        const int kt = k >> 6, c = (k >> 4) & 3, b = k & 15;
+        const size_t o = ((size_t)kt * Mpad + row) * FKT + ((c ^ ((row >> 2) & 3)) << 4) + b;
+        wt[o] = (int8_t)d0;
+        wt[plane_stride + o] = (int8_t)d1;
+        wt[2 * plane_stride + o] = (int8_t)d2;
+        if (in_sub) {
+            const size_t oq = ((size_t)kt * Msubpad + q) * FKT + ((c ^ ((q >> 2) & 3)) << 4) + b;
+            wt_sub[oq] = (int8_t)d0;
+            wt_sub[sub_stride + oq] = (int8_t)d1;
+            wt_sub[2 * sub_stride + oq] = (int8_t)d2;
+        }
     }
 }
 
@@ -205,18 +266,22 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             thr_s[tid] = (p < N) ? INFINITY : -INFINITY;  // no bound yet / padding never marks
         }
         __syncthreads();
-        if (tid == 0) {
-            int lo = 0x7fffffff, hi = -1;
-            for (int u = 0; u < 128; ++u) {
-                const int pj = prev_s[u];
-                if (pj >= 0) { lo = min(lo, pj); hi = max(hi, pj); }
+        if (wave == 0) {  // range of the seeds: the sweep starts at the chunk holding the lowest
+            const int a = prev_s[lane], b = prev_s[lane + 64];
+            int lo = min(a >= 0 ? a : 0x7fffffff, b >= 0 ? b : 0x7fffffff), hi = max(a, b);
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                lo = min(lo, __shfl_xor(lo, m, 64));
+                hi = max(hi, __shfl_xor(hi, m, 64));
             }
-            misc[0] = (hi >= 0) ? lo : 0;
-            misc[1] = hi;
+            if (lane == 0) {
+                misc[0] = (hi >= 0) ? lo : 0;
+                misc[1] = hi;
+            }
         }
         __syncthreads();
-        jlo = misc[0];
-        jhi = misc[1];
+        jlo = __builtin_amdgcn_readfirstlane(misc[0]);
+        jhi = __builtin_amdgcn_readfirstlane(misc[1]);
     }
 
     // per-lane sample constants (2 samples: one per 32-column tile)
@@ -246,38 +311,61 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const int dc = dcp ^ ((dr >> 2) & 3);  // source chunk for the linear LDS chunk (swizzle)
     const int64_t xpos = (p0 + dr < N) ? (p0 + dr) : (N - 1);
     const size_t xplane_stride = (size_t)N * dpad;
-    const size_t wplane_stride = (size_t)w_rows * dpad;  // rows of one W plane (all prototypes)
+    const size_t wplane_stride = (size_t)w_rows * dpad;  // w_rows: padded rows of one W plane
     const int8_t *xsrc = xplanes + (size_t)sample_at(xpos) * dpad + dc * 16;
-    const int nkt = dpad / FKT;
+    const int nkt = dpad / FKT;  // >= 2 (filter_dpad)
     const int nchunk = (M + BJ - 1) / BJ;
     const int ntile = nkt * nchunk;
     const int c0 = jlo / BJ;  // the sweep starts at the chunk holding the seeds
 
-    auto chunk_of = [&](int t) { int c = c0 + t / nkt; return c >= nchunk ? c - nchunk : c; };
-    auto issue = [&](int t) {
-        const int c_t = chunk_of(t), k0 = (t % nkt) * FKT, jc_t = c_t * BJ;
-        char *stage = smem + (t % FSTAGES) * L::STAGE;
+    // issue side of the ring: tile i_t = (chunk i_chunk, k-tile i_kt) goes to stage offset i_stage;
+    // the chunk tables ride with the first k-tile of their chunk (ring of 3, sequence i_cseq)
+    int i_kt = 0, i_chunk = c0, i_cseq = 0, i_stage = 0;
+    auto issue_x = [&]() {
+#if SWEEP_EXPERIMENT & 1
+        if (i_cseq + i_kt > 0) return;
+#endif
+        char *stage = smem + i_stage;
+        const int k0 = i_kt * FKT;
+#if SWEEP_EXPERIMENT & 32  // timing only: as if the X planes were stored k-tile-major in sweep order
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+            fdma16(xplanes + p * xplane_stride + ((size_t)i_kt * N + p0) * FKT + 1024 * wave + 16 * lane,
+                   stage + p * SW_PLANE + 1024 * wave);
+#else
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
             fdma16(xsrc + p * xplane_stride + k0, stage + p * SW_PLANE + 1024 * wave);
+#endif
+    };
+    auto issue_w = [&]() {  // also advances the issue counters
+        char *stage = smem + i_stage;
+        const int jc_t = i_chunk * BJ;
 #pragma unroll
         for (int u = 0; u < JT; ++u) {
-            int jw = jc_t + 128 * u + dr;
-            jw = jw < M ? jw : M - 1;
-            if constexpr (MODE == 1) jw *= jstride;
-            const int8_t *wsrc = wplanes + (size_t)jw * dpad + dc * 16 + k0;
+#if SWEEP_EXPERIMENT & 2
+            if (i_cseq + i_kt > 0) break;
+#endif
+            // k-tile-major planes: rows 16 w .. 16 w + 15 of this k-tile are one contiguous KiB
+            const int8_t *wsrc = wplanes + ((size_t)i_kt * w_rows + jc_t + 128 * u) * FKT + 1024 * wave + 16 * lane;
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
                 fdma16(wsrc + p * wplane_stride,
                        stage + NPL * SW_PLANE + p * L::W_PLANE + 8192 * u + 1024 * wave);
         }
-        if (t % nkt == 0) {  // this chunk's tables (1 KB pieces; the 8 waves cover them, twice for JT = 1)
+        if (i_kt == 0) {  // this chunk's tables (1 KB pieces; the 8 waves cover them, twice for JT = 1)
             constexpr int PIECES = 2 * JT;  // |w|^2 pieces, then ctab pieces
             const int piece = wave % PIECES, half = piece % JT;
             const int j2 = jc_t + 128 * half + 2 * lane;  // tables are padded to a multiple of 256 entries
-            char *tab = smem + L::OFF_TAB + ((t / nkt) % 3) * 2 * L::TAB;
+            char *tab = smem + L::OFF_TAB + i_cseq * 2 * L::TAB;
             if (piece >= JT) fdma16(ctab + j2, tab + L::TAB + 1024 * half);
             else fdma16(ww + j2, tab + 1024 * half);
+        }
+        i_stage = (i_stage == (FSTAGES - 1) * L::STAGE) ? 0 : i_stage + L::STAGE;
+        if (++i_kt == nkt) {
+            i_kt = 0;
+            i_chunk = (i_chunk + 1 == nchunk) ? 0 : i_chunk + 1;
+            i_cseq = (i_cseq == 2) ? 0 : i_cseq + 1;
         }
     };
 
@@ -294,6 +382,28 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         const int r = wj * 32 * JT + jt * 32 + lc;
         woff[jt] = NPL * SW_PLANE + r * FKT + ((lh ^ ((r >> 2) & 3)) * 16);
     }
+    struct Frags { v4i_t x[2][NPL], w[JT][NPL]; };
+    auto load_frags = [&](int stage_off, int ks, Frags &f) {
+        const char *stage = smem + stage_off;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+                f.w[jt][p] = *reinterpret_cast<const v4i_t *>(stage + p * L::W_PLANE + (woff[jt] ^ (ks * 32)));
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+                f.x[it][p] = *reinterpret_cast<const v4i_t *>(stage + p * SW_PLANE + (xoff[it] ^ (ks * 32)));
+        }
+    };
+    auto touch_frags = [&](const Frags &f) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) asm volatile("" ::"v"(f.w[jt][p]));
+#pragma unroll
+            for (int it = 0; it < 2; ++it) asm volatile("" ::"v"(f.x[it][p]));
+        }
+    };
     v16i_t acc[JT][2][NLV];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt)
@@ -303,53 +413,122 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             for (int lv = 0; lv < NLV; ++lv)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[jt][it][lv][r] = 0;
-
-    issue(0);
-    if (ntile > 1) issue(1);
-
-    for (int t = 0; t < ntile; ++t) {
-        if (t + 1 < ntile) {
-            if ((t + 1) % nkt == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_TILE + 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_TILE) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 2 < ntile) issue(t + 2);
-
-        const char *stage = smem + (t % FSTAGES) * L::STAGE;
+    // digit products of one k-step, level = plane(x) + plane(w); prototypes = rows (A), samples =
+    // cols (B).  `between(g)` runs after the g-th group of 2 JT products (DMA issue slots).
+    auto products = [&](const Frags &f, auto between) {
+        int g = 0;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            v4i_t xf[2][NPL], wf[JT][NPL];
+        for (int lv = 0; lv < NLV; ++lv)
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) {
+            for (int px = 0; px <= lv; ++px) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
-                    wf[jt][p] = *reinterpret_cast<const v4i_t *>(stage + p * L::W_PLANE + (woff[jt] ^ (ks * 32)));
 #pragma unroll
-                for (int it = 0; it < 2; ++it)
-                    xf[it][p] = *reinterpret_cast<const v4i_t *>(stage + p * SW_PLANE + (xoff[it] ^ (ks * 32)));
+                    for (int it = 0; it < 2; ++it)
+#if SWEEP_EXPERIMENT & 4
+                        acc[jt][it][lv][0] += f.w[jt][lv - px][0] ^ f.x[it][px][1];
+#else
+                        acc[jt][it][lv] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                            f.w[jt][lv - px], f.x[it][px], acc[jt][it][lv], 0, 0, 0);
+#endif
+                between(g++);
             }
-            // digit products, level = plane(x) + plane(w); prototypes = rows (A), samples = cols (B)
-#pragma unroll
-            for (int lv = 0; lv < NLV; ++lv)
-#pragma unroll
-                for (int px = 0; px <= lv; ++px)
-#pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                        for (int it = 0; it < 2; ++it)
-                            acc[jt][it][lv] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
-                                wf[jt][lv - px], xf[it][px], acc[jt][it][lv], 0, 0, 0);
-        }
+    };
+    auto wait_vm = [&](int n) {  // s_waitcnt vmcnt needs an immediate
+        if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n == DMA_TILE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_TILE) : "memory");
+        else if (n == DMA_TILE + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_TILE + 1) : "memory");
+        else if (n == 2 * DMA_TILE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_TILE + 1) : "memory");
+    };
 
-        if (t % nkt == nkt - 1) {
-            const int c_t = chunk_of(t), jc = c_t * BJ;
-            const double *ytab = reinterpret_cast<const double *>(smem + L::OFF_TAB + ((t / nkt) % 3) * 2 * L::TAB);
+    // ---- pipeline -------------------------------------------------------------------------------
+    // tile t lives in stage t % 3.  Per tile: [read k-step 1 of t] [products of k-step 0] -- own
+    // DMAs of t + 1 landed, own reads of t retired, barrier -- [DMA t + 3 into the stage of t]
+    // [read k-step 0 of t + 1] [products of k-step 1].  Every read has 2 JT (1 + .. + NLV)
+    // products of the other k-step in front of it, the barrier is the only point the matrix pipe
+    // drains.
+    const int n_pre = ntile < 3 ? ntile : 3;
+    for (int u = 0; u < n_pre; ++u) { issue_x(); issue_w(); }
+    {   // groups 1 and 2 may stay in flight (group 2 opens a chunk iff nkt == 2)
+        const int g2 = DMA_TILE + (nkt == 2 ? 1 : 0);
+        wait_vm(ntile > 2 ? DMA_TILE + g2 : (ntile > 1 ? DMA_TILE : 0));
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    Frags f0, f1;
+    load_frags(0, 0, f0);
+    const bool late_group = wave >= 4;
+    int r_kt = 0, r_cseq = 0, r_chunk = c0, r_stage = 0;
+    for (int t = 0; t < ntile; ++t) {
+        const int r_next = (r_stage == (FSTAGES - 1) * L::STAGE) ? 0 : r_stage + L::STAGE;
+        // DMA issue is staggered: waves 0-3 (one per SIMD) issue tile t + 3 behind the barrier of
+        // tile t, their SIMD mates 4-7 half a tile later, here -- a wave stalls ~100+ cycles per
+        // LDS-DMA instruction, and the matrix pipe only stays fed if its other wave is not stalled
+        // in the same place at the same time
+        const bool late_issue = late_group && t >= 1 && t + 2 < ntile;
+        products(f0, [&](int g) {  // the reads of k-step 1 go behind the first product group
+            if (g == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(r_stage, 1, f1);
+                touch_frags(f0);
+                if (late_issue) issue_x();
+            }
+            if (g == 1 && late_issue) issue_w();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        // (after the last tile this block is a no-op on stale data: no branch, so that the
+        // compiler's LDS wait counting sees one path)
+        if (t + 2 < ntile) wait_vm(DMA_TILE + ((r_kt + 2 == nkt) ? 1 : 0));
+        else wait_vm(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = !late_group && t + 3 < ntile;
+        products(f1, [&](int g) {
+            if (g == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(r_next, 0, f0);
+                // the compiler counts an LDS-DMA as a pending LDS event of unknown order and
+                // answers the next fragment use with lgkmcnt(0); retire f1 in ITS books here,
+                // before the DMAs, where the counted wait it emits is already satisfied
+                touch_frags(f1);
+                if (more) issue_x();
+            }
+            if (g == 1 && more) issue_w();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+
+        if (r_kt == nkt - 1) {
+#if SWEEP_EXPERIMENT & 8
+            if (t >= 0) {  // keep the products alive at (almost) no cost
+                int x = 0;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int lv = 0; lv < NLV; ++lv)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { x ^= acc[jt][it][lv][r]; acc[jt][it][lv][r] = 0; }
+#if !(SWEEP_EXPERIMENT & 64)
+                if (x == 0x12345678) misc[2] = x;
+#endif
+                r_kt = 0;
+                r_stage = r_next;
+                continue;
+            }
+#endif
+            const int jc = r_chunk * BJ;
+            const double *ytab = reinterpret_cast<const double *>(smem + L::OFF_TAB + r_cseq * 2 * L::TAB);
             const double *ctb = ytab + BJ;
             const bool has_prev = (jc <= jhi) && (jc + BJ - 1 >= jlo);
             (void)has_prev;
+            // everything derived from the lane's prototype offset is rebuilt here: hoisted out of
+            // the tile loop those 64 bit masks / table addresses cost the fragment registers
+            int jl0 = wj * 32 * JT + 4 * lh;
+            asm volatile("" : "+v"(jl0));
             if constexpr (MODE == 0) {
                 if (has_prev) {  // bound from the seed: thr_i = r~(i, seed_i) + 2 eps_i
 #pragma unroll
@@ -358,7 +537,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                         for (int it = 0; it < 2; ++it)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                const int jl = wj * 32 * JT + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                const int jl = jl0 + jt * 32 + (r & 3) + 8 * (r >> 2);
                                 if (jc + jl == prev_i[it]) {
                                     double T = (double)acc[jt][it][0][r] * 256.0 + (double)acc[jt][it][1][r];
                                     if constexpr (PLANES == 3) T = T * 256.0 + (double)acc[jt][it][2][r];
@@ -378,7 +557,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                 for (int it = 0; it < 2; ++it)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int jl = wj * 32 * JT + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int jl = jl0 + jt * 32 + (r & 3) + 8 * (r >> 2);
                         const int j = jc + jl;
                         double T = (double)acc[jt][it][0][r] * 256.0 + (double)acc[jt][it][1][r];
                         if constexpr (PLANES == 3) T = T * 256.0 + (double)acc[jt][it][2][r];
@@ -398,7 +577,13 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                     for (int lv = 0; lv < NLV; ++lv)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[jt][it][lv][r] = 0;
+            r_kt = 0;
+            r_chunk = (r_chunk + 1 == nchunk) ? 0 : r_chunk + 1;
+            r_cseq = (r_cseq == 2) ? 0 : r_cseq + 1;
+        } else {
+            ++r_kt;
         }
+        r_stage = r_next;
     }
 
     if constexpr (MODE == 1) {
@@ -458,24 +643,28 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 }
 
 // ---- 3. exact arg-min over the marked prototypes (float64 MFMA on gathered rows) -----------------
-// 128 gathered samples x SJ = 16 listed prototypes per step (the lists are short: a handful of
-// prototypes per workgroup on an organised map); 4 wavefronts x 32 samples, 3-stage LDS-DMA ring.
-constexpr int SJ = 16;
-constexpr int S_XT = 128 * KT * 4, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 KB + 2 KB
-
+// 128 gathered samples x SJ = 16 JTL listed prototypes per step; 4 wavefronts x 32 samples,
+// 3-stage LDS-DMA ring.  Three instantiations (JTL = 1, 2, 3) are launched back to back, each
+// takes the workgroups whose list length falls in its class (<= 16, 17..32, > 32) so that the
+// gathered X tile is streamed once for all but the longest lists.
+template <int JTL>
 __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     const float *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
     const double *__restrict__ W, int M, const double *__restrict__ ww,
     const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
     const uint32_t *__restrict__ ucount, int round_f32, int64_t *__restrict__ idx_out,
     double *__restrict__ dist_out) {
+    constexpr int SJ = 16 * JTL;
+    constexpr int S_XT = 128 * KT * 4, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 KB + 2 JTL KB
     __shared__ __attribute__((aligned(16))) char smem[3 * S_STAGE];
+    const int cnt = (int)ucount[blockIdx.x];
+    if (JTL == 1 ? (cnt > 16) : (JTL == 2 ? (cnt <= 16 || cnt > 32) : (cnt <= 32))) return;
+
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 4 waves x 32 samples
     const int lr = lane & 15, lq = lane >> 4;
     const int64_t p0 = (int64_t)blockIdx.x * 128;
-    const int cnt = (int)ucount[blockIdx.x];
     const uint16_t *list = ulist + (size_t)blockIdx.x * ulist_stride;
 
     double xi[2];
@@ -501,10 +690,12 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         p = p < N ? p : N - 1;
         xsrc[u] = X + (int64_t)order[p] * ldx + c * 4;
     }
-    // W tile: 16 rows x 128 B = 2 instructions, issued by waves 0 and 1: rows 8w..8w+7
-    const bool w_loader = wave < 2;
-    const int wr = 8 * (wave & 1) + (lane >> 3), wcp = lane & 7;
-    const int wc = (wcp ^ ((wr >> 1) & 7)) * 2;
+    // W tile: SJ rows x 128 B = 2 JTL instructions (8 rows each), issued by waves 0 .. 2 JTL - 1
+    // (JTL = 3: waves 0, 1 take two)
+    constexpr int W_INSTR = 2 * JTL;
+    const int n_wdma = (wave < W_INSTR - 4) ? 2 : (wave < W_INSTR ? 1 : 0);  // 6 instr: 2,2,1,1
+    const int wq0 = (wave < W_INSTR - 4) ? 2 * wave : (W_INSTR > 4 ? wave + (W_INSTR - 4) : wave);
+    const int wlr = lane >> 3, wcp = lane & 7;
 
     const int nkt = d / KT;
     const int nstep = (cnt + SJ - 1) / SJ;
@@ -515,16 +706,23 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         char *stage = smem + (t % 3) * S_STAGE;
 #pragma unroll
         for (int u = 0; u < 2; ++u) fdma16(xsrc[u] + k0, stage + 1024 * (2 * wave + u));
-        if (w_loader) {
+        for (int u = 0; u < n_wdma; ++u) {
+            const int q = wq0 + u, wr = 8 * q + wlr;
+            const int wc = (wcp ^ ((wr >> 1) & 7)) * 2;
             int pos = st * SJ + wr;
             pos = pos < cnt ? pos : cnt - 1;
             const int j = (int)list[pos];
-            fdma16(W + (int64_t)j * d + k0 + wc, stage + S_XT + 1024 * wave);
+            fdma16(W + (int64_t)j * d + k0 + wc, stage + S_XT + 1024 * q);
         }
     };
 
-    const int a_off = S_XT + lr * 128 + (lq & 1) * 8, a_swz = (lr >> 1) & 7;
-    int b_off[2], b_swz[2];
+    int a_off[JTL], a_swz[JTL], b_off[2], b_swz[2];
+#pragma unroll
+    for (int u = 0; u < JTL; ++u) {
+        const int ra = u * 16 + lr;
+        a_off[u] = S_XT + ra * 128 + (lq & 1) * 8;
+        a_swz[u] = (ra >> 1) & 7;
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int rb = wave * 32 + u * 16 + lr;
@@ -532,16 +730,20 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         b_swz[u] = (rb >> 1) & 3;
     }
 
-    d4_t acc[2] = {d4_t{0.0, 0.0, 0.0, 0.0}, d4_t{0.0, 0.0, 0.0, 0.0}};
+    d4_t acc[JTL][2];
+#pragma unroll
+    for (int jt = 0; jt < JTL; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
 
     if (ntile > 0) issue(0);
     if (ntile > 1) issue(1);
     int kt = 0, st = 0;
     for (int t = 0; t < ntile; ++t) {
-        // each wavefront waits for ITS OWN DMAs of tile t (3 per tile for the two that also load
-        // W, 2 for the others), the barrier then covers everybody's
+        // each wavefront waits for ITS OWN DMAs of tile t, the barrier then covers everybody's
         if (t + 1 < ntile) {
-            if (w_loader) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            if (n_wdma == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (n_wdma == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -552,35 +754,45 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         const char *stage = smem + (t % 3) * S_STAGE;
 #pragma unroll
         for (int ks = 0; ks < KT / 4; ++ks) {
-            const int ca = (2 * ks + (lq >> 1)) ^ a_swz;
-            const double a = *reinterpret_cast<const double *>(stage + a_off + ca * 16);
-            double b[2];
+            double a[JTL], b[2];
+#pragma unroll
+            for (int u = 0; u < JTL; ++u) {
+                const int ca = (2 * ks + (lq >> 1)) ^ a_swz[u];
+                a[u] = *reinterpret_cast<const double *>(stage + a_off[u] + ca * 16);
+            }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int cb = ks ^ b_swz[u];
                 b[u] = (double)*reinterpret_cast<const float *>(stage + b_off[u] + cb * 16);
             }
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
-                acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[it], acc[it], 0, 0, 0);
+            for (int jt = 0; jt < JTL; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+                    acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt], b[it], acc[jt][it],
+                                                                       0, 0, 0);
         }
         if (kt == nkt - 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int pos = st * SJ + 4 * r + lq;
-                if (pos < cnt) {
-                    const int j = (int)list[pos];
-                    const double y = ww[j];
+            for (int jt = 0; jt < JTL; ++jt)
 #pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        double rv = (xi[it] + (-2.0 * acc[it][r])) + y;
-                        if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
-                        best[it].push(rv, j);  // list ascends -> j ascends per lane
+                for (int r = 0; r < 4; ++r) {
+                    const int pos = st * SJ + jt * 16 + 4 * r + lq;
+                    if (pos < cnt) {
+                        const int j = (int)list[pos];
+                        const double y = ww[j];
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            double rv = (xi[it] + (-2.0 * acc[jt][it][r])) + y;
+                            if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
+                            best[it].push(rv, j);  // list ascends -> j ascends per lane
+                        }
                     }
                 }
-            }
-            acc[0] = d4_t{0.0, 0.0, 0.0, 0.0};
-            acc[1] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int jt = 0; jt < JTL; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
             kt = 0;
             ++st;
         } else {
@@ -619,7 +831,8 @@ static size_t carve_planes(PlaneBuf *b, char *base, int64_t rows, int64_t d) {
 }
 
 struct FilterWs {
-    PlaneBuf w;
+    int8_t *wt, *wt_sub;   // k-tile-major digit planes of the prototypes / of the pre-pass subset
+    double *wscale, *wl1;  // M each
     double *ctab, *yypad, *ctab_sub, *yy_sub, *summary;
     uint16_t *ulist;
     uint32_t *ucount;
@@ -629,15 +842,19 @@ struct FilterWs {
     int64_t nb, Mpad;
 };
 static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_t M) {
-    const int64_t Mpad = (M + 255) / 256 * 256, nb = (N + 127) / 128;
-    size_t off = carve_planes(f ? &f->w : nullptr, base, M, d);
+    const int64_t Mpad = (M + 255) / 256 * 256, nb = (N + 127) / 128, dpad = filter_dpad(d);
+    size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t ow = take((size_t)3 * Mpad * dpad), ows = take((size_t)3 * Mpad * dpad);
+    const size_t osc = take((size_t)M * 8), ol1 = take((size_t)M * 8);
     const size_t o0 = take((size_t)Mpad * 8), o1 = take((size_t)Mpad * 8), o2 = take(64);
     const size_t o8 = take((size_t)Mpad * 8), o9 = take((size_t)Mpad * 8);
     const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
     const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
     if (f) {
+        f->wt = (int8_t *)(base + ow); f->wt_sub = (int8_t *)(base + ows);
+        f->wscale = (double *)(base + osc); f->wl1 = (double *)(base + ol1);
         f->ctab = (double *)(base + o0); f->yypad = (double *)(base + o1);
         f->ctab_sub = (double *)(base + o8); f->yy_sub = (double *)(base + o9);
         f->summary = (double *)(base + o2); f->ulist = (uint16_t *)(base + o3);
@@ -752,24 +969,25 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     carve_filter(&f, (char *)workspace_dev, N, d, M);
     const int dpad = (int)filter_dpad(d);
     g_timer.mark(0, s);
-    int rc = launch_slice(W_dev, DBGSOM_F64, M, d, d, f.w, s);
-    if (rc != DBGSOM_OK) return rc;
     // the seed pre-pass looks at every `seed_stride`-th prototype (any seed keeps the result exact;
     // a coarser pre-pass is cheaper, its seeds are a little further from the minimum)
     if (seed_stride == 0) seed_stride = 4;
     while (seed_stride > 1 && (M + seed_stride - 1) / seed_stride < 128) seed_stride >>= 1;
-    const int Msub = (int)((M + seed_stride - 1) / seed_stride);
-    hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.w.scale, f.w.l1, ww_dev, (int)M,
+    const int Msub = (int)((M + seed_stride - 1) / seed_stride), Msubpad = (Msub + 255) / 256 * 256;
+    hipLaunchKernelGGL(slice_w_tiled_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, W_dev,
+                       (int)M, (int)d, dpad, (int)f.Mpad, seed_stride, Msubpad, f.wt, f.wt_sub,
+                       f.wscale, f.wl1);
+    hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.wscale, f.wl1, ww_dev, (int)M,
                        (int)f.Mpad, seed_stride, f.ctab, f.yypad, f.ctab_sub, f.yy_sub, f.summary);
     g_timer.mark(1, s);
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
         hipLaunchKernelGGL((sweep_i8_kernel<1, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
-                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yy_sub, f.ctab_sub,
+                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub,
                            f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
-                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, (int)M);
+                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad);
         g_timer.mark(2, s);
-        rc = launch_bucket_sort(f.seed, N, M, f.order, f.sort_ws, s);
+        const int rc = launch_bucket_sort(f.seed, N, M, f.order, f.sort_ws, s);
         if (rc != DBGSOM_OK) return rc;
         prev_idx_dev = f.seed;
         order_dev = f.order;
@@ -779,18 +997,23 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     g_timer.mark(3, s);
     if (sweep_planes == 3)
         hipLaunchKernelGGL((sweep_i8_kernel<0, 3, 1>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
-                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab,
+                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yypad, f.ctab,
                            f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int64_t *)nullptr, 1, (int)M);
+                           (int64_t *)nullptr, 1, (int)f.Mpad);
     else
         hipLaunchKernelGGL((sweep_i8_kernel<0, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
-                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.w.planes, f.yypad, f.ctab,
+                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yypad, f.ctab,
                            f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int64_t *)nullptr, 1, (int)M);
+                           (int64_t *)nullptr, 1, (int)f.Mpad);
     g_timer.mark(4, s);
-    hipLaunchKernelGGL(subset_exact_kernel, dim3((unsigned)f.nb), dim3(NT), 0, s,
-                       (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev,
-                       f.ulist, (int)f.Mpad, f.ucount, round_f32, idx_dev, dist_dev);
+#define DBGSOM_SUBSET(JTL)                                                                       \
+    hipLaunchKernelGGL(subset_exact_kernel<JTL>, dim3((unsigned)f.nb), dim3(NT), 0, s,              \
+                       (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev, \
+                       f.ulist, (int)f.Mpad, f.ucount, round_f32, idx_dev, dist_dev)
+    DBGSOM_SUBSET(1);
+    DBGSOM_SUBSET(2);
+    DBGSOM_SUBSET(3);
+#undef DBGSOM_SUBSET
     g_timer.mark(5, s);
     g_timer.valid = g_timer.enabled;
     return launch_status("filtered bmu kernels");
