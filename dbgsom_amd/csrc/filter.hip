@@ -30,6 +30,9 @@ constexpr double FQ = 8323072.0;  // 127 * 2^16
 constexpr int FKT = 64;           // bytes (= features) per plane row per LDS stage
 constexpr int FNT = 512;          // threads per sweep workgroup (8 wavefronts)
 constexpr int FSTAGES = 3;
+#ifndef SUBSET_EXPERIMENT
+#define SUBSET_EXPERIMENT 0  // timing experiments: 1 no X DMA, 2 no W DMA, 4 no MFMA
+#endif
 #ifndef SWEEP_EXPERIMENT
 #define SWEEP_EXPERIMENT 0  // timing experiments only: 1 no X DMA, 2 no W DMA, 4 no MFMA, 8 no chunk epilogue,
 // 32 contiguous X source addressing, 64 (with 8) products dead
@@ -258,6 +261,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     int jlo = 0, jhi = -1;
     if constexpr (MODE == 0) {
         for (int w = tid; w < nwords; w += FNT) mask[w] = 0u;
+#if SWEEP_EXPERIMENT & 128
+        if (tid == 0) misc[3] = 0;
+#endif
         if (tid < 128) {
             const int64_t p = p0 + tid;
             int pj = -1;
@@ -282,6 +288,59 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         __syncthreads();
         jlo = __builtin_amdgcn_readfirstlane(misc[0]);
         jhi = __builtin_amdgcn_readfirstlane(misc[1]);
+        // The seeds of a workgroup sit in one chunk, except where the sorted order crosses a chunk
+        // border.  There the samples whose seed lies in a later chunk would sweep the first chunk(s)
+        // without a bound (and mark all of them): give those samples their bound up front, from
+        // the same exact integer products by v_dot4 (4 threads per sample, K split by 16-byte
+        // chunks).  Rare path: a handful of workgroups per launch.
+        if (jlo / BJ != jhi / BJ) {
+            const int il = tid >> 2, q = tid & 3;
+            const int64_t p = p0 + il;
+            const int pj = prev_s[il];
+            const bool need = p < N && pj >= 0 && pj / BJ != jlo / BJ;
+            int a0 = 0, a1 = 0, a2 = 0;
+            const int64_t i = sample_at(p < N ? p : N - 1);
+            if (need) {
+                const size_t xps = (size_t)N * dpad, wps = (size_t)w_rows * dpad;
+                const int8_t *xr = xplanes + (size_t)i * dpad;
+                const int wsw = (pj >> 2) & 3;
+                for (int ch = q; ch < dpad / 16; ch += 4) {
+                    const int8_t *wr = wplanes + ((size_t)(ch >> 2) * w_rows + pj) * FKT + (((ch & 3) ^ wsw) << 4);
+                    v4i_t xv[PLANES], wv[PLANES];
+#pragma unroll
+                    for (int pl = 0; pl < PLANES; ++pl) {
+                        xv[pl] = *reinterpret_cast<const v4i_t *>(xr + pl * xps + ch * 16);
+                        wv[pl] = *reinterpret_cast<const v4i_t *>(wr + pl * wps);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a0 = __builtin_amdgcn_sdot4(xv[0][e], wv[0][e], a0, false);
+                        a1 = __builtin_amdgcn_sdot4(xv[0][e], wv[1][e], a1, false);
+                        a1 = __builtin_amdgcn_sdot4(xv[1][e], wv[0][e], a1, false);
+                        if constexpr (PLANES == 3) {
+                            a2 = __builtin_amdgcn_sdot4(xv[0][e], wv[2][e], a2, false);
+                            a2 = __builtin_amdgcn_sdot4(xv[1][e], wv[1][e], a2, false);
+                            a2 = __builtin_amdgcn_sdot4(xv[2][e], wv[0][e], a2, false);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 1; m <= 2; m <<= 1) {
+                a0 += __shfl_xor(a0, m, 64);
+                a1 += __shfl_xor(a1, m, 64);
+                a2 += __shfl_xor(a2, m, 64);
+            }
+            if (need && q == 0) {
+                double T = (double)a0 * 256.0 + (double)a1;
+                if constexpr (PLANES == 3) T = T * 256.0 + (double)a2;
+                else T = T * 256.0;
+                const double sv = sx[i], xv2 = xx[i];
+                const double e2 = 2.0 * filter_eps(sv, l1x[i], xv2, summary[0], summary[1], summary[2], d, PLANES);
+                thr_s[il] = ((xv2 + ww[pj]) - sv * (ctab[pj] * T)) + e2;
+            }
+            __syncthreads();
+        }
     }
 
     // per-lane sample constants (2 samples: one per 32-column tile)
@@ -529,46 +588,87 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             // the tile loop those 64 bit masks / table addresses cost the fragment registers
             int jl0 = wj * 32 * JT + 4 * lh;
             asm volatile("" : "+v"(jl0));
+            auto combine = [&](int a0, int a1, int a2) -> double {  // exact: |.| < 2^53
+                double T = (double)a0 * 256.0 + (double)a1;
+                if constexpr (PLANES == 3) T = T * 256.0 + (double)a2;
+                else T = T * 256.0;
+                return T;
+            };
             if constexpr (MODE == 0) {
                 if (has_prev) {  // bound from the seed: thr_i = r~(i, seed_i) + 2 eps_i
+                    // the seed's own products are picked by selects, not 64 divergent branches
 #pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
+                    for (int it = 0; it < 2; ++it) {
+                        int a0s = 0, a1s = 0, a2s = 0, jls = -1;
+                        const int want = prev_i[it] - jc;
 #pragma unroll
-                        for (int it = 0; it < 2; ++it)
+                        for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int jl = jl0 + jt * 32 + (r & 3) + 8 * (r >> 2);
-                                if (jc + jl == prev_i[it]) {
-                                    double T = (double)acc[jt][it][0][r] * 256.0 + (double)acc[jt][it][1][r];
-                                    if constexpr (PLANES == 3) T = T * 256.0 + (double)acc[jt][it][2][r];
-                                    else T = T * 256.0;
-                                    thr_s[wi * 64 + it * 32 + lc] =
-                                        ((xx_i[it] + ytab[jl]) - s_i[it] * (ctb[jl] * T)) + eps2_i[it];
-                                }
+                                const bool sel = jl == want;
+                                a0s = sel ? acc[jt][it][0][r] : a0s;
+                                a1s = sel ? acc[jt][it][1][r] : a1s;
+                                if constexpr (PLANES == 3) a2s = sel ? acc[jt][it][2][r] : a2s;
+                                jls = sel ? jl : jls;
                             }
+                        if (jls >= 0)
+                            thr_s[wi * 64 + it * 32 + lc] =
+                                ((xx_i[it] + ytab[jls]) - s_i[it] * (ctb[jls] * combine(a0s, a1s, a2s))) + eps2_i[it];
+                    }
                     __syncthreads();
 #pragma unroll
                     for (int it = 0; it < 2; ++it) thr_i[it] = thr_s[wi * 64 + it * 32 + lc];
                 }
             }
+            // all table reads and compares of a 32-prototype tile first (bits), the LDS atomics
+            // after them: a possible atomic between two elements pins every later table read
+            // behind it and exposes one LDS round trip per element
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
+            for (int jt = 0; jt < JT; ++jt) {
+                uint32_t hit = 0;
+#if SWEEP_EXPERIMENT & 128
+                uint32_t hit2 = 0;  // one bit per (sample, prototype) pair
+#endif
 #pragma unroll
-                for (int it = 0; it < 2; ++it)
+                for (int g = 0; g < 4; ++g) {
+                    double y4[4], c4[4];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int jl = jl0 + jt * 32 + (r & 3) + 8 * (r >> 2);
-                        const int j = jc + jl;
-                        double T = (double)acc[jt][it][0][r] * 256.0 + (double)acc[jt][it][1][r];
-                        if constexpr (PLANES == 3) T = T * 256.0 + (double)acc[jt][it][2][r];
-                        else T = T * 256.0;
-                        const double rv = (xx_i[it] + ytab[jl]) - s_i[it] * (ctb[jl] * T);
-                        if constexpr (MODE == 0) {
-                            if (j < M && rv <= thr_i[it]) atomicOr(&mask[j >> 5], 1u << (j & 31));
-                        } else {
-                            if (j < M && rv < bestv[it]) { bestv[it] = rv; bestj[it] = j * jstride; }
+                    for (int i = 0; i < 4; ++i) {
+                        y4[i] = ytab[jl0 + jt * 32 + 8 * g + i];
+                        c4[i] = ctb[jl0 + jt * 32 + 8 * g + i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * g + i;
+                        const int j = jc + jl0 + jt * 32 + 8 * g + i;
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            const double T = combine(acc[jt][it][0][r], acc[jt][it][1][r],
+                                                     PLANES == 3 ? acc[jt][it][NLV - 1][r] : 0);
+                            const double rv = (xx_i[it] + y4[i]) - s_i[it] * (c4[i] * T);
+                            if constexpr (MODE == 0) {
+                                hit |= (uint32_t)(j < M && rv <= thr_i[it]) << r;
+#if SWEEP_EXPERIMENT & 128
+                                hit2 |= (uint32_t)(j < M && rv <= thr_i[it]) << (2 * r + it);
+#endif
+                            } else {
+                                if (j < M && rv < bestv[it]) { bestv[it] = rv; bestj[it] = j * jstride; }
+                            }
                         }
                     }
+                }
+                if constexpr (MODE == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = jc + jl0 + jt * 32 + (r & 3) + 8 * (r >> 2);
+                        if ((hit >> r) & 1u) atomicOr(&mask[j >> 5], 1u << (j & 31));
+                    }
+#if SWEEP_EXPERIMENT & 128
+                    atomicAdd(&misc[3], __popc(hit2));
+#endif
+                }
+            }
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
@@ -639,6 +739,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             base += __shfl(pre, 63, 64);
         }
         if (lane == 0) ucount[blockIdx.x] = base;
+#if SWEEP_EXPERIMENT & 128
+        if (lane == 0) ucount[blockIdx.x] = (uint32_t)misc[3];  // pairs instead of list length
+#endif
     }
 }
 
@@ -657,6 +760,9 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     constexpr int SJ = 16 * JTL;
     constexpr int S_XT = 128 * KT * 4, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 KB + 2 JTL KB
     __shared__ __attribute__((aligned(16))) char smem[3 * S_STAGE];
+#if SUBSET_EXPERIMENT & 32
+    return;
+#endif
     const int cnt = (int)ucount[blockIdx.x];
     if (JTL == 1 ? (cnt > 16) : (JTL == 2 ? (cnt <= 16 || cnt > 32) : (cnt <= 32))) return;
 
@@ -701,19 +807,38 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     const int nstep = (cnt + SJ - 1) / SJ;
     const int ntile = nkt * nstep;
 
-    auto issue = [&](int t) {
-        const int st = t / nkt, k0 = (t - st * nkt) * KT;
-        char *stage = smem + (t % 3) * S_STAGE;
+    // issue side of the ring.  The W rows of a step (their list entries are global loads) are
+    // looked up ONCE per step, not per tile: a load in front of every DMA would drain the whole
+    // ring (vmcnt counts in order) each tile.
+    int i_kt = 0, i_step = 0, i_stage = 0;
+    const double *wrow[2] = {W, W};
+    auto issue = [&]() {
+        if (i_kt == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (u < n_wdma) {
+                    const int wr = 8 * (wq0 + u) + wlr;
+                    const int wc = (wcp ^ ((wr >> 1) & 7)) * 2;
+                    int pos = i_step * SJ + wr;
+                    pos = pos < cnt ? pos : cnt - 1;
+                    wrow[u] = W + (int64_t)list[pos] * d + wc;
+                }
+        }
+        const int k0 = i_kt * KT;
+        char *stage = smem + i_stage;
+#if SUBSET_EXPERIMENT & 1
+        if (i_step + i_kt < 3)
+#endif
 #pragma unroll
         for (int u = 0; u < 2; ++u) fdma16(xsrc[u] + k0, stage + 1024 * (2 * wave + u));
-        for (int u = 0; u < n_wdma; ++u) {
-            const int q = wq0 + u, wr = 8 * q + wlr;
-            const int wc = (wcp ^ ((wr >> 1) & 7)) * 2;
-            int pos = st * SJ + wr;
-            pos = pos < cnt ? pos : cnt - 1;
-            const int j = (int)list[pos];
-            fdma16(W + (int64_t)j * d + k0 + wc, stage + S_XT + 1024 * q);
-        }
+#if SUBSET_EXPERIMENT & 2
+        if (i_step + i_kt < 3)
+#endif
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (u < n_wdma) fdma16(wrow[u] + k0, stage + S_XT + 1024 * (wq0 + u));
+        i_stage = (i_stage == 2 * S_STAGE) ? 0 : i_stage + S_STAGE;
+        if (++i_kt == nkt) { i_kt = 0; ++i_step; }
     };
 
     int a_off[JTL], a_swz[JTL], b_off[2], b_swz[2];
@@ -736,9 +861,9 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
 #pragma unroll
         for (int it = 0; it < 2; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
 
-    if (ntile > 0) issue(0);
-    if (ntile > 1) issue(1);
-    int kt = 0, st = 0;
+    if (ntile > 0) issue();
+    if (ntile > 1) issue();
+    int kt = 0, st = 0, r_stage = 0;
     for (int t = 0; t < ntile; ++t) {
         // each wavefront waits for ITS OWN DMAs of tile t, the barrier then covers everybody's
         if (t + 1 < ntile) {
@@ -748,13 +873,21 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#if !(SUBSET_EXPERIMENT & 16)
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
-        if (t + 2 < ntile) issue(t + 2);
-        const char *stage = smem + (t % 3) * S_STAGE;
+        if (t + 2 < ntile) issue();
+        const char *stage = smem + r_stage;
+        r_stage = (r_stage == 2 * S_STAGE) ? 0 : r_stage + S_STAGE;
 #pragma unroll
         for (int ks = 0; ks < KT / 4; ++ks) {
             double a[JTL], b[2];
+#if SUBSET_EXPERIMENT & 8
+#pragma unroll
+            for (int u = 0; u < JTL; ++u) a[u] = xi[0] + u;
+            b[0] = xi[1]; b[1] = xi[0];
+#else
 #pragma unroll
             for (int u = 0; u < JTL; ++u) {
                 const int ca = (2 * ks + (lq >> 1)) ^ a_swz[u];
@@ -765,30 +898,45 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
                 const int cb = ks ^ b_swz[u];
                 b[u] = (double)*reinterpret_cast<const float *>(stage + b_off[u] + cb * 16);
             }
+#endif
 #pragma unroll
             for (int jt = 0; jt < JTL; ++jt)
 #pragma unroll
                 for (int it = 0; it < 2; ++it)
+#if SUBSET_EXPERIMENT & 4
+                    acc[jt][it][0] += a[jt] * b[it];
+#else
                     acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt], b[it], acc[jt][it],
                                                                        0, 0, 0);
+#endif
         }
         if (kt == nkt - 1) {
+            // list entries and |w|^2 of the lane's candidates, 4 at a time: loads first (clamped
+            // positions, no branches), so that their latencies overlap
 #pragma unroll
-            for (int jt = 0; jt < JTL; ++jt)
+            for (int jt = 0; jt < JTL; ++jt) {
+                int jv[4];
+                double yv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pos = st * SJ + jt * 16 + 4 * r + lq;
+                    jv[r] = (int)list[pos < cnt ? pos : cnt - 1];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[r] = ww[jv[r]];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int pos = st * SJ + jt * 16 + 4 * r + lq;
                     if (pos < cnt) {
-                        const int j = (int)list[pos];
-                        const double y = ww[j];
 #pragma unroll
                         for (int it = 0; it < 2; ++it) {
-                            double rv = (xi[it] + (-2.0 * acc[jt][it][r])) + y;
+                            double rv = (xi[it] + (-2.0 * acc[jt][it][r])) + yv[r];
                             if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
-                            best[it].push(rv, j);  // list ascends -> j ascends per lane
+                            best[it].push(rv, jv[r]);  // list ascends -> j ascends per lane
                         }
                     }
                 }
+            }
 #pragma unroll
             for (int jt = 0; jt < JTL; ++jt)
 #pragma unroll

@@ -348,7 +348,8 @@ def test_bf16_storage_matches_oracle_on_rounded_samples(hip, o, N, d, M):
 
 
 @pytest.mark.parametrize("N,d,rows,cols", [(20000, 784, 16, 16), (5000, 64, 18, 19),
-                                            (12345, 128, 17, 17)])
+                                            (12345, 128, 17, 17), (9000, 208, 30, 30),
+                                            (6000, 48, 23, 23)])
 def test_filtered_search_is_identical_to_exact(o, N, d, rows, cols):
     """The int8-MFMA filter + exact re-evaluation must reproduce the all-pairs float64 search bit
     for bit, over several epochs of a moving map (the filter uses the previous epoch's winners)."""
@@ -362,13 +363,16 @@ def test_filtered_search_is_identical_to_exact(o, N, d, rows, cols):
     exact = HipBackend(algorithm="exact").load(X)
     filt = HipBackend(algorithm="filtered_hint").load(X)   # pre-pass at epoch 0, hints afterwards
     stateless = HipBackend(algorithm="filtered").load(X)   # pre-pass every epoch
+    three = HipBackend(algorithm="filtered").load(X)       # the six-product (3 digit planes) sweep
+    three.sweep_planes = 3
     sigma = 0.2 * np.sqrt(M)
     We, Wf = W, W
     for e in range(5):
         re_ = exact.epoch(We, hop, sigma, gamma, "compact", True)
         rf = filt.epoch(Wf, hop, sigma, gamma, "compact", True)
         rs = stateless.epoch(We, hop, sigma, gamma, "compact", True)
-        for r in (rf, rs):
+        r3 = three.epoch(We, hop, sigma, gamma, "compact", True)
+        for r in (rf, rs, r3):
             assert np.array_equal(re_.winners, r.winners), f"epoch {e}"
             assert np.array_equal(re_.distances, r.distances), f"epoch {e}"
             assert np.array_equal(re_.new_weights, r.new_weights), f"epoch {e}"

@@ -37,6 +37,11 @@ ms = (ctypes.c_double * 5)()
 _native.call("dbgsom_bmu_filtered_stage_ms", ms)
 c = hip.filter_counts()
 err = globals().get("err", "")
+c = np.asarray(c)
+pad = np.where(c <= 16, 16, np.where(c <= 32, 32, (c + 47) // 48 * 48))
+print("classes: <=16 %d  17..32 %d  33..48 %d  >48 %d (max %d);  padded candidates/WG %.1f -> exact-stage MFMA floor %.3f ms at 78.6 TF"
+      % ((c <= 16).sum(), ((c > 16) & (c <= 32)).sum(), ((c > 32) & (c <= 48)).sum(), (c > 48).sum(), c.max(),
+         pad.mean(), pad.sum() * 128.0 * d * 2 / 78.6e12 * 1e3))
 print(os.environ.get("DBGSOM_LIB", "default"), name,
       dict(zip(("slice_w", "prepass", "sort", "sweep", "exact"), [round(float(v), 3) for v in ms])),
       "cand mean %.1f" % c.mean(), err)
