@@ -380,51 +380,40 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     // issue side of the ring: tile i_t = (chunk i_chunk, k-tile i_kt) goes to stage offset i_stage;
     // the chunk tables ride with the first k-tile of their chunk (ring of 3, sequence i_cseq)
     int i_kt = 0, i_chunk = c0, i_cseq = 0, i_stage = 0;
-    auto issue_x = [&]() {
-#if SWEEP_EXPERIMENT & 1
-        if (i_cseq + i_kt > 0) return;
-#endif
+    // the DMA_TILE = NPL (1 + JT) LDS-DMA instructions of a tile: X plane p (op p), then W rows
+    // 128 u .. of plane p (op NPL + u NPL + p); ops [lo, hi) are issued, hi == DMA_TILE also
+    // sends the chunk tables (first k-tile of a chunk) and advances the issue counters
+    auto issue_ops = [&](int lo, int hi) {
         char *stage = smem + i_stage;
-        const int k0 = i_kt * FKT;
-#if SWEEP_EXPERIMENT & 32  // timing only: as if the X planes were stored k-tile-major in sweep order
+        const int k0 = i_kt * FKT, jc_t = i_chunk * BJ;
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
-            fdma16(xplanes + p * xplane_stride + ((size_t)i_kt * N + p0) * FKT + 1024 * wave + 16 * lane,
-                   stage + p * SW_PLANE + 1024 * wave);
-#else
-#pragma unroll
-        for (int p = 0; p < NPL; ++p)
-            fdma16(xsrc + p * xplane_stride + k0, stage + p * SW_PLANE + 1024 * wave);
-#endif
-    };
-    auto issue_w = [&]() {  // also advances the issue counters
-        char *stage = smem + i_stage;
-        const int jc_t = i_chunk * BJ;
+            if (p >= lo && p < hi) fdma16(xsrc + p * xplane_stride + k0, stage + p * SW_PLANE + 1024 * wave);
 #pragma unroll
         for (int u = 0; u < JT; ++u) {
-#if SWEEP_EXPERIMENT & 2
-            if (i_cseq + i_kt > 0) break;
-#endif
             // k-tile-major planes: rows 16 w .. 16 w + 15 of this k-tile are one contiguous KiB
             const int8_t *wsrc = wplanes + ((size_t)i_kt * w_rows + jc_t + 128 * u) * FKT + 1024 * wave + 16 * lane;
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
-                fdma16(wsrc + p * wplane_stride,
-                       stage + NPL * SW_PLANE + p * L::W_PLANE + 8192 * u + 1024 * wave);
+                if (NPL + u * NPL + p >= lo && NPL + u * NPL + p < hi)
+                    fdma16(wsrc + p * wplane_stride,
+                           stage + NPL * SW_PLANE + p * L::W_PLANE + 8192 * u + 1024 * wave);
         }
-        if (i_kt == 0) {  // this chunk's tables (1 KB pieces; the 8 waves cover them, twice for JT = 1)
-            constexpr int PIECES = 2 * JT;  // |w|^2 pieces, then ctab pieces
-            const int piece = wave % PIECES, half = piece % JT;
-            const int j2 = jc_t + 128 * half + 2 * lane;  // tables are padded to a multiple of 256 entries
-            char *tab = smem + L::OFF_TAB + i_cseq * 2 * L::TAB;
-            if (piece >= JT) fdma16(ctab + j2, tab + L::TAB + 1024 * half);
-            else fdma16(ww + j2, tab + 1024 * half);
-        }
-        i_stage = (i_stage == (FSTAGES - 1) * L::STAGE) ? 0 : i_stage + L::STAGE;
-        if (++i_kt == nkt) {
-            i_kt = 0;
-            i_chunk = (i_chunk + 1 == nchunk) ? 0 : i_chunk + 1;
-            i_cseq = (i_cseq == 2) ? 0 : i_cseq + 1;
+        if (hi == DMA_TILE) {
+            if (i_kt == 0) {  // this chunk's tables (1 KB pieces; the 8 waves cover them, twice for JT = 1)
+                constexpr int PIECES = 2 * JT;  // |w|^2 pieces, then ctab pieces
+                const int piece = wave % PIECES, half = piece % JT;
+                const int j2 = jc_t + 128 * half + 2 * lane;  // tables are padded to a multiple of 256 entries
+                char *tab = smem + L::OFF_TAB + i_cseq * 2 * L::TAB;
+                if (piece >= JT) fdma16(ctab + j2, tab + L::TAB + 1024 * half);
+                else fdma16(ww + j2, tab + 1024 * half);
+            }
+            i_stage = (i_stage == (FSTAGES - 1) * L::STAGE) ? 0 : i_stage + L::STAGE;
+            if (++i_kt == nkt) {
+                i_kt = 0;
+                i_chunk = (i_chunk + 1 == nchunk) ? 0 : i_chunk + 1;
+                i_cseq = (i_cseq == 2) ? 0 : i_cseq + 1;
+            }
         }
     };
 
@@ -508,7 +497,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     // products of the other k-step in front of it, the barrier is the only point the matrix pipe
     // drains.
     const int n_pre = ntile < 3 ? ntile : 3;
-    for (int u = 0; u < n_pre; ++u) { issue_x(); issue_w(); }
+    for (int u = 0; u < n_pre; ++u) issue_ops(0, DMA_TILE);
     {   // groups 1 and 2 may stay in flight (group 2 opens a chunk iff nkt == 2)
         const int g2 = DMA_TILE + (nkt == 2 ? 1 : 0);
         wait_vm(ntile > 2 ? DMA_TILE + g2 : (ntile > 1 ? DMA_TILE : 0));
@@ -517,34 +506,46 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     asm volatile("" ::: "memory");
     Frags f0, f1;
     load_frags(0, 0, f0);
-    const bool late_group = wave >= 4;
+    const int dma_slot = wave >= 4 ? 1 : 0;  // product group behind which this wave issues DMAs
+#if SWEEP_EXPERIMENT & 256
+    __shared__ unsigned wstamps[2 * 13 * 5];
+    const uint64_t w_start = __builtin_amdgcn_s_memtime();
+    const bool stamper = lane == 0 && (wave == 0 || wave == 4);
+#define WSTAMP(k) if (stamper && t >= 16 && t < 29) wstamps[(wave >> 2) * 65 + (t - 16) * 5 + (k)] = (unsigned)__builtin_amdgcn_s_memtime()
+#else
+#define WSTAMP(k)
+#endif
     int r_kt = 0, r_cseq = 0, r_chunk = c0, r_stage = 0;
     for (int t = 0; t < ntile; ++t) {
         const int r_next = (r_stage == (FSTAGES - 1) * L::STAGE) ? 0 : r_stage + L::STAGE;
-        // DMA issue is staggered: waves 0-3 (one per SIMD) issue tile t + 3 behind the barrier of
-        // tile t, their SIMD mates 4-7 half a tile later, here -- a wave stalls ~100+ cycles per
-        // LDS-DMA instruction, and the matrix pipe only stays fed if its other wave is not stalled
-        // in the same place at the same time
-        const bool late_issue = late_group && t >= 1 && t + 2 < ntile;
+        // DMA issue: a wave stalls ~100+ cycles per LDS-DMA instruction and issues in order, so
+        // the matrix pipe only stays fed while its other wave is NOT stalled in the same place.
+        // Every wave issues half of a tile's DMAs in each half tile (front half of tile t + 3
+        // behind the barrier, back half in the first half of the next tile); waves 0-3 (one per
+        // SIMD) do so behind the first product group, their SIMD mates 4-7 behind the second.
+        WSTAMP(0);
+        const bool back_now = t >= 1 && t + 2 < ntile;
         products(f0, [&](int g) {  // the reads of k-step 1 go behind the first product group
             if (g == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_frags(r_stage, 1, f1);
                 touch_frags(f0);
-                if (late_issue) issue_x();
             }
-            if (g == 1 && late_issue) issue_w();
+            if (g == dma_slot && back_now) issue_ops(DMA_TILE / 2, DMA_TILE);
             __builtin_amdgcn_sched_barrier(0);
         });
         __builtin_amdgcn_sched_barrier(0);
         // (after the last tile this block is a no-op on stale data: no branch, so that the
         // compiler's LDS wait counting sees one path)
+        WSTAMP(1);
         if (t + 2 < ntile) wait_vm(DMA_TILE + ((r_kt + 2 == nkt) ? 1 : 0));
         else wait_vm(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WSTAMP(2);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const bool more = !late_group && t + 3 < ntile;
+        WSTAMP(3);
+        const bool front_now = t + 3 < ntile;
         products(f1, [&](int g) {
             if (g == 0) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -553,12 +554,12 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                 // answers the next fragment use with lgkmcnt(0); retire f1 in ITS books here,
                 // before the DMAs, where the counted wait it emits is already satisfied
                 touch_frags(f1);
-                if (more) issue_x();
             }
-            if (g == 1 && more) issue_w();
+            if (g == dma_slot && front_now) issue_ops(0, DMA_TILE / 2);
             __builtin_amdgcn_sched_barrier(0);
         });
 
+        WSTAMP(4);
         if (r_kt == nkt - 1) {
 #if SWEEP_EXPERIMENT & 8
             if (t >= 0) {  // keep the products alive at (almost) no cost
@@ -739,6 +740,13 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             base += __shfl(pre, 63, 64);
         }
         if (lane == 0) ucount[blockIdx.x] = base;
+#if SWEEP_EXPERIMENT & 256
+        {   // stamps of waves 0 and 4 behind the list: uint32 at uint16 offset 512 of this row
+            unsigned *dbg = reinterpret_cast<unsigned *>(out + 512);
+            for (int e = lane; e < 130; e += 64) dbg[e] = wstamps[e] - wstamps[0];
+            if (lane == 0) dbg[130] = (unsigned)(__builtin_amdgcn_s_memtime() - w_start);
+        }
+#endif
 #if SWEEP_EXPERIMENT & 128
         if (lane == 0) ucount[blockIdx.x] = (uint32_t)misc[3];  // pairs instead of list length
 #endif
@@ -759,9 +767,18 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     double *__restrict__ dist_out) {
     constexpr int SJ = 16 * JTL;
     constexpr int S_XT = 128 * KT * 4, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 KB + 2 JTL KB
+#if SUBSET_EXPERIMENT & 64
+    __shared__ __attribute__((aligned(16))) char smem[6 * S_STAGE];  // halves the blocks per CU
+#else
     __shared__ __attribute__((aligned(16))) char smem[3 * S_STAGE];
+#endif
 #if SUBSET_EXPERIMENT & 32
     return;
+#endif
+#if SUBSET_EXPERIMENT & 128
+    const uint64_t t_start = __builtin_amdgcn_s_memtime();
+    const uint64_t r_start = __builtin_amdgcn_s_memrealtime();
+    uint64_t t_loop = 0, t_loop_end = 0;
 #endif
     const int cnt = (int)ucount[blockIdx.x];
     if (JTL == 1 ? (cnt > 16) : (JTL == 2 ? (cnt <= 16 || cnt > 32) : (cnt <= 32))) return;
@@ -864,7 +881,16 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     if (ntile > 0) issue();
     if (ntile > 1) issue();
     int kt = 0, st = 0, r_stage = 0;
+#if SUBSET_EXPERIMENT & 128
+    t_loop = __builtin_amdgcn_s_memtime();
+    __shared__ unsigned stamps[13 * 5];
+    const bool stamper = tid == 0;
+#define STAMP(k) if (stamper && t >= 8 && t < 21) stamps[(t - 8) * 5 + (k)] = (unsigned)__builtin_amdgcn_s_memtime()
+#else
+#define STAMP(k)
+#endif
     for (int t = 0; t < ntile; ++t) {
+        STAMP(0);
         // each wavefront waits for ITS OWN DMAs of tile t, the barrier then covers everybody's
         if (t + 1 < ntile) {
             if (n_wdma == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -873,11 +899,14 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        STAMP(1);
 #if !(SUBSET_EXPERIMENT & 16)
         __builtin_amdgcn_s_barrier();
 #endif
+        STAMP(2);
         asm volatile("" ::: "memory");
         if (t + 2 < ntile) issue();
+        STAMP(3);
         const char *stage = smem + r_stage;
         r_stage = (r_stage == 2 * S_STAGE) ? 0 : r_stage + S_STAGE;
 #pragma unroll
@@ -910,6 +939,7 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
                                                                        0, 0, 0);
 #endif
         }
+        STAMP(4);
         if (kt == nkt - 1) {
             // list entries and |w|^2 of the lane's candidates, 4 at a time: loads first (clamped
             // positions, no branches), so that their latencies overlap
@@ -959,9 +989,20 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
             double dv = sqrt(best[it].v[0]);
             if (round_f32) dv = (double)(float)dv;
             idx_out[isamp[it]] = (best[it].j[0] == 0x7fffffff) ? (int64_t)-1 : (int64_t)best[it].j[0];
+#if SUBSET_EXPERIMENT & 128
+            if (dv == -1.0) dist_out[isamp[it]] = dv;
+#else
             dist_out[isamp[it]] = dv;
+#endif
         }
     }
+#if SUBSET_EXPERIMENT & 128
+    t_loop_end = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (tid < 65 && p0 + 128 <= N) dist_out[p0 + tid] = (double)(stamps[tid] - stamps[0]);
+        if (tid == 65 && p0 + 128 <= N) dist_out[p0 + 65] = (double)cnt;
+        if (tid == 66 && p0 + 128 <= N) { dist_out[p0 + 66] = (double)r_start; dist_out[p0 + 67] = (double)__builtin_amdgcn_s_memrealtime(); dist_out[p0 + 68] = (double)__smid(); dist_out[p0 + 69] = (double)(__builtin_amdgcn_s_memtime() - t_start); dist_out[p0 + 70] = (double)(t_loop - t_start); dist_out[p0 + 71] = (double)(t_loop_end - t_start); }
+#endif
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
@@ -1166,6 +1207,14 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     g_timer.valid = g_timer.enabled;
     return launch_status("filtered bmu kernels");
 }
+
+#if SWEEP_EXPERIMENT & 256
+size_t dbgsom_debug_ulist_offset(int64_t N, int64_t d, int64_t M) {
+    FilterWs f;
+    carve_filter(&f, (char *)nullptr, N, d, M);
+    return (size_t)((char *)f.ulist - (char *)nullptr);
+}
+#endif
 
 /* diagnostics: sizes of the per-workgroup candidate lists of the last dbgsom_bmu_filtered call */
 int dbgsom_bmu_filtered_counts(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
