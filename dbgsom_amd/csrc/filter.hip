@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__rest
 // per-prototype tables of the sweep, padded with zeros to Mpad (a multiple of 128) entries:
 // ctab_j = 2 t_j 2^16 / F^2 (so r~ = (xx+yy) - s_i ctab_j T), yypad_j = |w_j|^2;
 // summary[0] = max_j l1_j, summary[1] = max_j t_j, summary[2] = max_j |w_j|^2
-// (ctab_sub, yy_sub: the same for every `stride`-th prototype -- the seed pre-pass)
+// (ctab_sub, yy_sub: the same for every `stride`-th prototype -- the seed pre-pass;
+//  ictab, yctab: 1 / (ctab tscale) and |w|^2 / (ctab tscale), the form the marking test uses)
 __global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict__ tw,
                                                        const double *__restrict__ l1w,
                                                        const double *__restrict__ ww, int M,
@@ -148,6 +149,8 @@ __global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict_
                                                        double *__restrict__ yypad,
                                                        double *__restrict__ ctab_sub,
                                                        double *__restrict__ yy_sub,
+                                                       double tscale, double *__restrict__ ictab,
+                                                       double *__restrict__ yctab,
                                                        double *__restrict__ summary) {
     __shared__ double r0[1024], r1[1024], r2[1024];
     const int t = threadIdx.x;
@@ -157,9 +160,17 @@ __global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict_
         const bool in_sub = js < M;
         ctab_sub[j] = in_sub ? 2.0 * tw[js] * 65536.0 / (FQ * FQ) : 0.0;
         yy_sub[j] = in_sub ? ww[js] : 0.0;
-        if (j >= M) { ctab[j] = 0.0; yypad[j] = 0.0; continue; }
-        ctab[j] = 2.0 * tw[j] * 65536.0 / (FQ * FQ);
+        if (j >= M) { ctab[j] = 0.0; yypad[j] = 0.0; ictab[j] = 0.0; yctab[j] = 0.0; continue; }
+        const double cj = 2.0 * tw[j] * 65536.0 / (FQ * FQ);
+        ctab[j] = cj;
         yypad[j] = ww[j];
+        // the marking test r~ <= thr in the form (xx - thr) / c' + |w|^2 / c' <= s T', c' = c tscale
+        // (T' = T / tscale is what the sweep's accumulators give without the last shift); a
+        // prototype too small for a finite reciprocal is simply always marked
+        const double cs = cj * tscale;
+        const bool ok = cs > 1e-280;
+        ictab[j] = ok ? 1.0 / cs : 0.0;
+        yctab[j] = ok ? ww[j] / cs : -INFINITY;
         a = fmax(a, l1w[j]); b = fmax(b, tw[j]); c = fmax(c, ww[j]);
     }
     r0[t] = a; r1[t] = b; r2[t] = c;
@@ -236,7 +247,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx,
     const double *__restrict__ l1x, const double *__restrict__ xx, int64_t N, int d, int dpad,
     const int8_t *__restrict__ wplanes, const double *__restrict__ ww,
-    const double *__restrict__ ctab, const double *__restrict__ summary, int M,
+    const double *__restrict__ ctab, const double *__restrict__ yraw,
+    const double *__restrict__ craw, const double *__restrict__ summary, int M,
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount,
     int64_t *__restrict__ seed, int jstride, int w_rows) {
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             int pj = -1;
             if (p < N) pj = (int)prev[sample_at(p)];
             prev_s[tid] = (pj >= 0 && pj < M) ? pj : -1;
-            thr_s[tid] = (p < N) ? INFINITY : -INFINITY;  // no bound yet / padding never marks
+            thr_s[tid] = (p < N) ? -INFINITY : INFINITY;  // A = |x|^2 - thr: no bound yet / padding never marks
         }
         __syncthreads();
         if (wave == 0) {  // range of the seeds: the sweep starts at the chunk holding the lowest
@@ -337,15 +349,16 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                 else T = T * 256.0;
                 const double sv = sx[i], xv2 = xx[i];
                 const double e2 = 2.0 * filter_eps(sv, l1x[i], xv2, summary[0], summary[1], summary[2], d, PLANES);
-                thr_s[il] = ((xv2 + ww[pj]) - sv * (ctab[pj] * T)) + e2;
+                thr_s[il] = (sv * (craw[pj] * T) - yraw[pj]) - e2;  // = |x|^2 - (r~_seed + 2 eps)
             }
             __syncthreads();
         }
     }
 
     // per-lane sample constants (2 samples: one per 32-column tile)
-    double s_i[2], xx_i[2], eps2_i[2], thr_i[2];
-    int prev_i[2];
+    // A_i = |x_i|^2 - thr_i with thr_i = r~(i, seed_i) + 2 eps_i the bound from the seed: the marking
+    // test r~_ij <= thr_i only needs A_i, and A_i = s c T - |w_seed|^2 - 2 eps needs no |x_i|^2
+    double s_i[2], eps2_i[2], A_i[2];
     const double l1w_max = summary[0], t_max = summary[1], yy_max = summary[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -353,13 +366,11 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         const int64_t p = p0 + il;
         const int64_t i = sample_at(p < N ? p : N - 1);
         s_i[it] = sx[i];
-        xx_i[it] = xx[i];
         if constexpr (MODE == 0) {
-            eps2_i[it] = 2.0 * filter_eps(s_i[it], l1x[i], xx_i[it], l1w_max, t_max, yy_max, d, PLANES);
-            prev_i[it] = prev_s[il];
-            thr_i[it] = thr_s[il];
+            eps2_i[it] = 2.0 * filter_eps(s_i[it], l1x[i], xx[i], l1w_max, t_max, yy_max, d, PLANES);
+            A_i[it] = thr_s[il];
         } else {
-            eps2_i[it] = 0.0; prev_i[it] = -1; thr_i[it] = 0.0;
+            eps2_i[it] = 0.0; A_i[it] = 0.0;
         }
     }
     double bestv[2] = {INFINITY, INFINITY};  // MODE 1: running arg-min of r~
@@ -383,20 +394,25 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     // the DMA_TILE = NPL (1 + JT) LDS-DMA instructions of a tile: X plane p (op p), then W rows
     // 128 u .. of plane p (op NPL + u NPL + p); ops [lo, hi) are issued, hi == DMA_TILE also
     // sends the chunk tables (first k-tile of a chunk) and advances the issue counters
+    const uint32_t lane_off = 1024u * wave + 16u * lane;  // this lane's 16 bytes of a wave's contiguous KiB
     auto issue_ops = [&](int lo, int hi) {
         char *stage = smem + i_stage;
         const int k0 = i_kt * FKT, jc_t = i_chunk * BJ;
+        // (the plane strides are made opaque here: hoisted out of the tile loop, "row + p stride"
+        // per plane and operand costs the registers the fragments need)
+        size_t xps = xplane_stride, wps = wplane_stride;
+        asm volatile("" : "+s"(xps), "+s"(wps));
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
-            if (p >= lo && p < hi) fdma16(xsrc + p * xplane_stride + k0, stage + p * SW_PLANE + 1024 * wave);
+            if (p >= lo && p < hi) fdma16(xsrc + p * xps + k0, stage + p * SW_PLANE + 1024 * wave);
 #pragma unroll
         for (int u = 0; u < JT; ++u) {
             // k-tile-major planes: rows 16 w .. 16 w + 15 of this k-tile are one contiguous KiB
-            const int8_t *wsrc = wplanes + ((size_t)i_kt * w_rows + jc_t + 128 * u) * FKT + 1024 * wave + 16 * lane;
+            const int8_t *wsrc = wplanes + ((size_t)i_kt * w_rows + jc_t + 128 * u) * FKT + lane_off;
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
                 if (NPL + u * NPL + p >= lo && NPL + u * NPL + p < hi)
-                    fdma16(wsrc + p * wplane_stride,
+                    fdma16(wsrc + p * wps,
                            stage + NPL * SW_PLANE + p * L::W_PLANE + 8192 * u + 1024 * wave);
         }
         if (hi == DMA_TILE) {
@@ -549,7 +565,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         products(f1, [&](int g) {
             if (g == 0) {
                 __builtin_amdgcn_sched_barrier(0);
-                load_frags(r_next, 0, f0);
+                // (before a chunk epilogue the next tile's fragments are fetched after it: they
+                // would only sit in 32 registers the epilogue needs)
+                if (r_kt != nkt - 1) load_frags(r_next, 0, f0);
                 // the compiler counts an LDS-DMA as a pending LDS event of unknown order and
                 // answers the next fragment use with lgkmcnt(0); retire f1 in ITS books here,
                 // before the DMAs, where the counted wait it emits is already satisfied
@@ -601,7 +619,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #pragma unroll
                     for (int it = 0; it < 2; ++it) {
                         int a0s = 0, a1s = 0, a2s = 0, jls = -1;
-                        const int want = prev_i[it] - jc;
+                        const int want = prev_s[wi * 64 + it * 32 + lc] - jc;
 #pragma unroll
                         for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
@@ -615,16 +633,18 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                             }
                         if (jls >= 0)
                             thr_s[wi * 64 + it * 32 + lc] =
-                                ((xx_i[it] + ytab[jls]) - s_i[it] * (ctb[jls] * combine(a0s, a1s, a2s))) + eps2_i[it];
+                                (s_i[it] * (craw[jc + jls] * combine(a0s, a1s, a2s)) - yraw[jc + jls]) - eps2_i[it];
                     }
                     __syncthreads();
 #pragma unroll
-                    for (int it = 0; it < 2; ++it) thr_i[it] = thr_s[wi * 64 + it * 32 + lc];
+                    for (int it = 0; it < 2; ++it) A_i[it] = thr_s[wi * 64 + it * 32 + lc];
                 }
             }
             // all table reads and compares of a 32-prototype tile first (bits), the LDS atomics
             // after them: a possible atomic between two elements pins every later table read
-            // behind it and exposes one LDS round trip per element
+            // behind it and exposes one LDS round trip per element.
+            // MODE 0 tests r~ <= thr as (xx - thr) ic_j + yc_j <= s T' with the tables in reciprocal
+            // form (6 float64 operations per pair instead of 9); MODE 1 needs r~ itself.
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
                 uint32_t hit = 0;
@@ -645,15 +665,18 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                         const int j = jc + jl0 + jt * 32 + 8 * g + i;
 #pragma unroll
                         for (int it = 0; it < 2; ++it) {
-                            const double T = combine(acc[jt][it][0][r], acc[jt][it][1][r],
-                                                     PLANES == 3 ? acc[jt][it][NLV - 1][r] : 0);
-                            const double rv = (xx_i[it] + y4[i]) - s_i[it] * (c4[i] * T);
                             if constexpr (MODE == 0) {
-                                hit |= (uint32_t)(j < M && rv <= thr_i[it]) << r;
+                                double Tp = (double)acc[jt][it][0][r] * 256.0 + (double)acc[jt][it][1][r];
+                                if constexpr (PLANES == 3) Tp = Tp * 256.0 + (double)acc[jt][it][2][r];
+                                const bool pass = (A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp;
+                                hit |= (uint32_t)(j < M && pass) << r;
 #if SWEEP_EXPERIMENT & 128
-                                hit2 |= (uint32_t)(j < M && rv <= thr_i[it]) << (2 * r + it);
+                                hit2 |= (uint32_t)(j < M && pass) << (2 * r + it);
 #endif
                             } else {
+                                const double T = combine(acc[jt][it][0][r], acc[jt][it][1][r],
+                                                         PLANES == 3 ? acc[jt][it][NLV - 1][r] : 0);
+                                const double rv = y4[i] - s_i[it] * (c4[i] * T);  // r~ - |x_i|^2
                                 if (j < M && rv < bestv[it]) { bestv[it] = rv; bestj[it] = j * jstride; }
                             }
                         }
@@ -681,6 +704,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             r_kt = 0;
             r_chunk = (r_chunk + 1 == nchunk) ? 0 : r_chunk + 1;
             r_cseq = (r_cseq == 2) ? 0 : r_cseq + 1;
+            load_frags(r_next, 0, f0);
         } else {
             ++r_kt;
         }
@@ -1022,7 +1046,7 @@ static size_t carve_planes(PlaneBuf *b, char *base, int64_t rows, int64_t d) {
 struct FilterWs {
     int8_t *wt, *wt_sub;   // k-tile-major digit planes of the prototypes / of the pre-pass subset
     double *wscale, *wl1;  // M each
-    double *ctab, *yypad, *ctab_sub, *yy_sub, *summary;
+    double *ctab, *yypad, *ctab_sub, *yy_sub, *ictab, *yctab, *summary;
     uint16_t *ulist;
     uint32_t *ucount;
     int64_t *seed;     // N   arg-min of the coarse pre-pass (when the caller has no previous winners)
@@ -1038,6 +1062,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t osc = take((size_t)M * 8), ol1 = take((size_t)M * 8);
     const size_t o0 = take((size_t)Mpad * 8), o1 = take((size_t)Mpad * 8), o2 = take(64);
     const size_t o8 = take((size_t)Mpad * 8), o9 = take((size_t)Mpad * 8);
+    const size_t o10 = take((size_t)Mpad * 8), o11 = take((size_t)Mpad * 8);
     const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
     const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
@@ -1046,6 +1071,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
         f->wscale = (double *)(base + osc); f->wl1 = (double *)(base + ol1);
         f->ctab = (double *)(base + o0); f->yypad = (double *)(base + o1);
         f->ctab_sub = (double *)(base + o8); f->yy_sub = (double *)(base + o9);
+        f->ictab = (double *)(base + o10); f->yctab = (double *)(base + o11);
         f->summary = (double *)(base + o2); f->ulist = (uint16_t *)(base + o3);
         f->ucount = (uint32_t *)(base + o4); f->seed = (int64_t *)(base + o5);
         f->order = (int32_t *)(base + o6); f->sort_ws = base + o7; f->nb = nb; f->Mpad = Mpad;
@@ -1167,13 +1193,14 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                        (int)M, (int)d, dpad, (int)f.Mpad, seed_stride, Msubpad, f.wt, f.wt_sub,
                        f.wscale, f.wl1);
     hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.wscale, f.wl1, ww_dev, (int)M,
-                       (int)f.Mpad, seed_stride, f.ctab, f.yypad, f.ctab_sub, f.yy_sub, f.summary);
+                       (int)f.Mpad, seed_stride, f.ctab, f.yypad, f.ctab_sub, f.yy_sub,
+                       sweep_planes == 2 ? 256.0 : 1.0, f.ictab, f.yctab, f.summary);
     g_timer.mark(1, s);
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
         hipLaunchKernelGGL((sweep_i8_kernel<1, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub,
-                           f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
+                           f.yy_sub, f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
                            f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad);
         g_timer.mark(2, s);
         const int rc = launch_bucket_sort(f.seed, N, M, f.order, f.sort_ws, s);
@@ -1186,13 +1213,13 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     g_timer.mark(3, s);
     if (sweep_planes == 3)
         hipLaunchKernelGGL((sweep_i8_kernel<0, 3, 1>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
-                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yypad, f.ctab,
-                           f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
+                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab,
+                           f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
                            (int64_t *)nullptr, 1, (int)f.Mpad);
     else
         hipLaunchKernelGGL((sweep_i8_kernel<0, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
-                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yypad, f.ctab,
-                           f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
+                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab,
+                           f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
                            (int64_t *)nullptr, 1, (int)f.Mpad);
     g_timer.mark(4, s);
 #define DBGSOM_SUBSET(JTL)                                                                       \
