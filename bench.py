@@ -45,7 +45,7 @@ I8_MFMA_PEAK_TOPS = 5033.0   # 256 x 4 x 2.4 GHz x 65536 op / 32 cycles (v_mfma_
 # HBM-side bytes of one full-sweep launch at C4 from the PMC passes committed under profiles/
 # (FETCH_SIZE x 2 per the gfx950 correction); not measurable inside this process.  Keyed by the
 # number of digit planes the sweep reads (2 -> sweep_i8_kernel<0,2,2>, 3 -> sweep_i8_kernel<0,3,1>)
-SWEEP_TRAFFIC_C4_BYTES = {2: 7.93e9, 3: 2.42e10}
+SWEEP_TRAFFIC_C4_BYTES = {2: 7.90e9, 3: 2.42e10}
 SWEEP_KERNEL = {2: "sweep_i8_kernel<0,2,2>", 3: "sweep_i8_kernel<0,3,1>"}
 SWEEP_PRODUCTS = {2: 3, 3: 6}   # int8 digit products kept per (sample, prototype, k)
 
