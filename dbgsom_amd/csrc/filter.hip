@@ -30,6 +30,7 @@ constexpr double FQ = 8323072.0;  // 127 * 2^16
 constexpr int FKT = 64;           // bytes (= features) per plane row per LDS stage
 constexpr int FNT = 512;          // threads per sweep workgroup (8 wavefronts)
 constexpr int FSTAGES = 3;
+constexpr int PREPASS_KTILES = 3;  // k-tiles the seed pre-pass samples (evenly spaced)
 #ifndef SUBSET_EXPERIMENT
 #define SUBSET_EXPERIMENT 0  // timing experiments: 1 no X DMA, 2 no W DMA, 4 no MFMA
 #endif
@@ -92,10 +93,12 @@ __global__ __launch_bounds__(256) void slice_rows_kernel(const T *__restrict__ A
 // seed pre-pass.  Pad rows are never initialised: the sweep masks j >= M.
 __global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__restrict__ W, int M, int d,
                                                             int dpad, int Mpad, int stride,
-                                                            int Msubpad, int8_t *__restrict__ wt,
+                                                            int Msubpad, int nkt_used,
+                                                            int8_t *__restrict__ wt,
                                                             int8_t *__restrict__ wt_sub,
                                                             double *__restrict__ scale,
-                                                            double *__restrict__ l1) {
+                                                            double *__restrict__ l1,
+                                                            double *__restrict__ yy_part) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -115,6 +118,16 @@ __global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__rest
     const size_t plane_stride = (size_t)Mpad * dpad, sub_stride = (size_t)Msubpad * dpad;
     const bool in_sub = (row % stride) == 0;
     const int q = row / stride;
+    if (in_sub) {  // |w|^2 over the k-tiles the seed pre-pass looks at (prepass_tile below)
+        const int nkt_full = dpad / FKT;
+        double p2 = 0.0;
+        for (int u = 0; u < nkt_used; ++u) {
+            const int k = ((u * nkt_full) / nkt_used) * FKT + lane;
+            if (k < d) p2 += a[k] * a[k];
+        }
+        for (int off = 32; off > 0; off >>= 1) p2 += __shfl_xor(p2, off, 64);
+        if (lane == 0) yy_part[q] = p2;
+    }
     for (int k = lane; k < dpad; k += 64) {
         int v = 0;
         if (k < d) v = (int)rint(a[k] / s * FQ);
@@ -143,7 +156,8 @@ __global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__rest
 //  ictab, yctab: 1 / (ctab tscale) and |w|^2 / (ctab tscale), the form the marking test uses)
 __global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict__ tw,
                                                        const double *__restrict__ l1w,
-                                                       const double *__restrict__ ww, int M,
+                                                       const double *__restrict__ ww,
+                                                       const double *__restrict__ yy_part, int M,
                                                        int Mpad, int stride,
                                                        double *__restrict__ ctab,
                                                        double *__restrict__ yypad,
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict_
         const long js = (long)j * stride;  // j-th entry of the strided tables
         const bool in_sub = js < M;
         ctab_sub[j] = in_sub ? 2.0 * tw[js] * 65536.0 / (FQ * FQ) : 0.0;
-        yy_sub[j] = in_sub ? ww[js] : 0.0;
+        yy_sub[j] = in_sub ? yy_part[j] : 0.0;
         if (j >= M) { ctab[j] = 0.0; yypad[j] = 0.0; ictab[j] = 0.0; yctab[j] = 0.0; continue; }
         const double cj = 2.0 * tw[j] * 65536.0 / (FQ * FQ);
         ctab[j] = cj;
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const double *__restrict__ craw, const double *__restrict__ summary, int M,
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount,
-    int64_t *__restrict__ seed, int jstride, int w_rows) {
+    int64_t *__restrict__ seed, int jstride, int w_rows, int nkt_used) {
     using L = SweepLds<PLANES, JT>;
     constexpr int NPL = PLANES, NLV = PLANES, BJ = L::BJ;
     constexpr int DMA_TILE = NPL * (1 + JT);  // DMA instructions per wave per tile
@@ -383,7 +397,11 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const size_t xplane_stride = (size_t)N * dpad;
     const size_t wplane_stride = (size_t)w_rows * dpad;  // w_rows: padded rows of one W plane
     const int8_t *xsrc = xplanes + (size_t)sample_at(xpos) * dpad + dc * 16;
-    const int nkt = dpad / FKT;  // >= 2 (filter_dpad)
+    // MODE 1 may look at a sample of the k-tiles only (nkt_used of them, evenly spaced): seeds
+    // need not be good, only cheap -- see dbgsom_bmu_filtered
+    const int nkt_full = dpad / FKT;  // >= 2 (filter_dpad)
+    const int nkt = (MODE == 1 && nkt_used >= 2 && nkt_used < nkt_full) ? nkt_used : nkt_full;
+    auto tile_of = [&](int kt) { return MODE == 1 ? (kt * nkt_full) / nkt : kt; };
     const int nchunk = (M + BJ - 1) / BJ;
     const int ntile = nkt * nchunk;
     const int c0 = jlo / BJ;  // the sweep starts at the chunk holding the seeds
@@ -397,7 +415,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const uint32_t lane_off = 1024u * wave + 16u * lane;  // this lane's 16 bytes of a wave's contiguous KiB
     auto issue_ops = [&](int lo, int hi) {
         char *stage = smem + i_stage;
-        const int k0 = i_kt * FKT, jc_t = i_chunk * BJ;
+        const int i_tile = tile_of(i_kt);
+        const int k0 = i_tile * FKT, jc_t = i_chunk * BJ;
         // (the plane strides are made opaque here: hoisted out of the tile loop, "row + p stride"
         // per plane and operand costs the registers the fragments need)
         size_t xps = xplane_stride, wps = wplane_stride;
@@ -408,7 +427,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #pragma unroll
         for (int u = 0; u < JT; ++u) {
             // k-tile-major planes: rows 16 w .. 16 w + 15 of this k-tile are one contiguous KiB
-            const int8_t *wsrc = wplanes + ((size_t)i_kt * w_rows + jc_t + 128 * u) * FKT + lane_off;
+            const int8_t *wsrc = wplanes + ((size_t)i_tile * w_rows + jc_t + 128 * u) * FKT + lane_off;
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
                 if (NPL + u * NPL + p >= lo && NPL + u * NPL + p < hi)
@@ -781,7 +800,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 // 128 gathered samples x SJ = 16 JTL listed prototypes per step; 4 wavefronts x 32 samples,
 // 3-stage LDS-DMA ring.  Three instantiations (JTL = 1, 2, 3) are launched back to back, each
 // takes the workgroups whose list length falls in its class (<= 16, 17..32, > 32) so that the
-// gathered X tile is streamed once for all but the longest lists.
+// gathered X tile is streamed once for all but the longest lists (a fourth class of 64 was
+// measured: no gain at C3 / C4, slower at C2).
 template <int JTL>
 __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     const float *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
@@ -1046,7 +1066,7 @@ static size_t carve_planes(PlaneBuf *b, char *base, int64_t rows, int64_t d) {
 struct FilterWs {
     int8_t *wt, *wt_sub;   // k-tile-major digit planes of the prototypes / of the pre-pass subset
     double *wscale, *wl1;  // M each
-    double *ctab, *yypad, *ctab_sub, *yy_sub, *ictab, *yctab, *summary;
+    double *ctab, *yypad, *ctab_sub, *yy_sub, *ictab, *yctab, *yy_part, *summary;
     uint16_t *ulist;
     uint32_t *ucount;
     int64_t *seed;     // N   arg-min of the coarse pre-pass (when the caller has no previous winners)
@@ -1062,7 +1082,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t osc = take((size_t)M * 8), ol1 = take((size_t)M * 8);
     const size_t o0 = take((size_t)Mpad * 8), o1 = take((size_t)Mpad * 8), o2 = take(64);
     const size_t o8 = take((size_t)Mpad * 8), o9 = take((size_t)Mpad * 8);
-    const size_t o10 = take((size_t)Mpad * 8), o11 = take((size_t)Mpad * 8);
+    const size_t o10 = take((size_t)Mpad * 8), o11 = take((size_t)Mpad * 8), o12 = take((size_t)Mpad * 8);
     const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
     const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
@@ -1072,6 +1092,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
         f->ctab = (double *)(base + o0); f->yypad = (double *)(base + o1);
         f->ctab_sub = (double *)(base + o8); f->yy_sub = (double *)(base + o9);
         f->ictab = (double *)(base + o10); f->yctab = (double *)(base + o11);
+        f->yy_part = (double *)(base + o12);
         f->summary = (double *)(base + o2); f->ulist = (uint16_t *)(base + o3);
         f->ucount = (uint32_t *)(base + o4); f->seed = (int64_t *)(base + o5);
         f->order = (int32_t *)(base + o6); f->sort_ws = base + o7; f->nb = nb; f->Mpad = Mpad;
@@ -1189,10 +1210,19 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     if (seed_stride == 0) seed_stride = 4;
     while (seed_stride > 1 && (M + seed_stride - 1) / seed_stride < 128) seed_stride >>= 1;
     const int Msub = (int)((M + seed_stride - 1) / seed_stride), Msubpad = (Msub + 255) / 256 * 256;
+    // ... and at PREPASS_KTILES k-tiles (64 features each) spread evenly over the row, with the
+    // matching partial |w|^2: on every workload measured the candidate lists are as short as with
+    // all features, the pre-pass costs 0.35 instead of 0.75 ms at C4 (DBGSOM_PREPASS_KTILES=0: all)
+    static const int prepass_env = [] {
+        const char *e = getenv("DBGSOM_PREPASS_KTILES");
+        return e ? atoi(e) : PREPASS_KTILES;
+    }();
+    const int nkt_full = dpad / FKT;
+    const int nkt_used = (prepass_env >= 2 && prepass_env < nkt_full) ? prepass_env : nkt_full;
     hipLaunchKernelGGL(slice_w_tiled_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, W_dev,
-                       (int)M, (int)d, dpad, (int)f.Mpad, seed_stride, Msubpad, f.wt, f.wt_sub,
-                       f.wscale, f.wl1);
-    hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.wscale, f.wl1, ww_dev, (int)M,
+                       (int)M, (int)d, dpad, (int)f.Mpad, seed_stride, Msubpad, nkt_used, f.wt,
+                       f.wt_sub, f.wscale, f.wl1, f.yy_part);
+    hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.wscale, f.wl1, ww_dev, f.yy_part, (int)M,
                        (int)f.Mpad, seed_stride, f.ctab, f.yypad, f.ctab_sub, f.yy_sub,
                        sweep_planes == 2 ? 256.0 : 1.0, f.ictab, f.yctab, f.summary);
     g_timer.mark(1, s);
@@ -1201,7 +1231,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         hipLaunchKernelGGL((sweep_i8_kernel<1, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub,
                            f.yy_sub, f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
-                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad);
+                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad, nkt_used);
         g_timer.mark(2, s);
         const int rc = launch_bucket_sort(f.seed, N, M, f.order, f.sort_ws, s);
         if (rc != DBGSOM_OK) return rc;
@@ -1215,12 +1245,12 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         hipLaunchKernelGGL((sweep_i8_kernel<0, 3, 1>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab,
                            f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int64_t *)nullptr, 1, (int)f.Mpad);
+                           (int64_t *)nullptr, 1, (int)f.Mpad, 0);
     else
         hipLaunchKernelGGL((sweep_i8_kernel<0, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab,
                            f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int64_t *)nullptr, 1, (int)f.Mpad);
+                           (int64_t *)nullptr, 1, (int)f.Mpad, 0);
     g_timer.mark(4, s);
 #define DBGSOM_SUBSET(JTL)                                                                       \
     hipLaunchKernelGGL(subset_exact_kernel<JTL>, dim3((unsigned)f.nb), dim3(NT), 0, s,              \
