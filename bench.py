@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the batch-SOM hot path on MI355X: samples/sec/epoch (BMU + update).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|c5]
 
 One "step" = one epoch of the hot path (reference dbgsom/BaseSom.py:403-407: BMU search, sample
 kernel, per-neuron sums, [all-reduce], neighbourhood smoothing, convergence norm, per-neuron
@@ -39,7 +39,10 @@ WORKLOADS = {
     "c4": (1_000_000, 784, 32, 32, 1004, "Synthetic N=1e6 d=784 fp32, M=1024 (32x32)"),
     "c3": (1_000_000, 128, 45, 45, 1003, "Synthetic Gaussian blobs N=1e6 d=128 fp32, M=2025 (45x45)"),
     "c2": (60_000, 784, 22, 23, 1002, "Fashion-MNIST stand-in 60k x 784 fp32, M=506 (22x23)"),
+    # one GPU's shard of BASELINE config 5 (N=4e6 over 8 GPUs), samples resident as bfloat16
+    "c5": (500_000, 2048, 64, 64, 1005, "Synthetic N=4e6/8 d=2048 bf16, M=4096 (64x64)"),
 }
+BF16_WORKLOADS = ("c5",)
 F64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 cycles (v_mfma_f64_16x16x4_f64)
 I8_MFMA_PEAK_TOPS = 5033.0   # 256 x 4 x 2.4 GHz x 65536 op / 32 cycles (v_mfma_i32_32x32x32_i8, dense)
 # HBM-side bytes of one full-sweep launch at C4 from the PMC passes committed under profiles/
@@ -269,6 +272,8 @@ def main():
         n_gpu = args.samples_per_gpu
     M = rows * cols
     X = make_shard(torch, n_gpu, d, seed + rank, device)
+    if args.workload in BF16_WORKLOADS:
+        X = X.to(torch.bfloat16)  # storage dtype of the workload; HipBackend.load_device keeps it
 
     # frozen map: M rows of rank 0's shard, Manhattan hop distances, epoch-0 sigma, gamma = 1/var
     ctl = torch.zeros(M * d + 1, dtype=torch.float64, device=device)
@@ -328,7 +333,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": cfg_name, "samples_per_gpu": n_gpu, "features": d,
-                       "prototypes": M, "x_storage": "f32", "sharding": f"rows/{world}",
+                       "prototypes": M, "x_storage": "bf16" if args.workload in BF16_WORKLOADS else "f32",
+                       "sharding": f"rows/{world}",
                        "map": "frozen (same prototypes every step)",
                        "bmu_algorithm": args.algorithm},
             "roofline": roof,
@@ -344,7 +350,7 @@ def main():
             out["fine_phase"] = fine
         if args.cpu_sample > 0 and world == 1:  # the CPU baseline is reported at N = 1 only
             ns = min(args.cpu_sample, n_gpu)
-            out["cpu_baseline"] = cpu_baseline(args.workload, X[:ns].cpu().numpy(),
+            out["cpu_baseline"] = cpu_baseline(args.workload, X[:ns].float().cpu().numpy(),
                                                W0.cpu().numpy(), hop, sigma, gamma, n_gpu)
             out["gpu_vs_cpu"] = (n_gpu * args.steps / elapsed) / out["cpu_baseline"]["value"]
         print(json.dumps(out))

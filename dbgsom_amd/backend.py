@@ -325,12 +325,26 @@ class HipBackend(HotPathBackend):
 
     def _reset_filter_state(self):
         self._planes = self._prev_idx = self._order = None
+        self._X32 = None
+
+    def _bmu_samples(self):
+        """(samples, dtype) the BMU kernels read.  bfloat16-resident samples get a float32 copy
+        (exact widening, made once): the LDS-DMA kernels and the filtered search are written for
+        float32 rows, and at 288 GB of HBM the copy (4 bytes per element next to the 2 of the
+        resident array) is cheaper than a third tile format; the accumulate step, which is bound
+        by the bytes of X it reads, keeps using the bfloat16 array."""
+        if isinstance(self._x_np_dtype, str):
+            if self._X32 is None:
+                self._X32 = self._X.float()
+            return self._X32, np.dtype(np.float32)
+        return self._X, self._x_np_dtype
 
     def _filter_applies(self, M):
         if self.algorithm == "auto" and self._filter_backoff > 0:
             return False
-        return (self.algorithm != "exact" and not isinstance(self._x_np_dtype, str)
-                and self._x_np_dtype == np.float32 and self._X.shape[1] % 16 == 0
+        return (self.algorithm != "exact"
+                and (isinstance(self._x_np_dtype, str) or self._x_np_dtype == np.float32)
+                and self._X.shape[1] % 16 == 0
                 and self.FILTER_MIN_PROTOTYPES <= M <= _native.MAX_PROTOTYPES)
 
     def _hint(self):
@@ -344,17 +358,18 @@ class HipBackend(HotPathBackend):
         torch = self._torch
         N, d = self._X.shape
         M = Wd.shape[0]
+        X32, _ = self._bmu_samples()
         if self._planes is None:  # digit planes of X: once per resident sample set
             nbytes = self._lib.dbgsom_filter_planes_bytes(N, d)
             self._planes = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            _native.call("dbgsom_filter_prepare", self._p(self._X), _native.F32, N, d, d,
+            _native.call("dbgsom_filter_prepare", self._p(X32), _native.F32, N, d, d,
                          self._p(self._planes), nbytes, self._stream())
         idx = torch.empty((N, 1), dtype=torch.int64, device=self.device)
         dist = torch.empty((N, 1), dtype=torch.float64, device=self.device)
         need = self._lib.dbgsom_bmu_filtered_workspace_bytes(N, d, M)
         ws = self._buf("filter", need)
         prev_p, order_p = self._hint()
-        self._timed_call("bmu", "dbgsom_bmu_filtered", self._p(self._X), _native.F32, N, d, d,
+        self._timed_call("bmu", "dbgsom_bmu_filtered", self._p(X32), _native.F32, N, d, d,
                          self._p(self._xx), self._p(self._planes), self._p(Wd), M, self._p(wwd),
                          prev_p, order_p, int(self.seed_stride), int(self.sweep_planes), round_f32,
                          self._p(idx),
@@ -396,17 +411,18 @@ class HipBackend(HotPathBackend):
         W = np.asarray(W)
         if X is None:
             self._require_loaded()
-            Xd, xxd, xdtype = self._X, self._xx, self._x_np_dtype
+            (Xd, xdtype), xxd = self._bmu_samples(), self._xx
+            src_dtype = self._x_np_dtype  # bf16-resident samples: no float32 rounding of distances
         else:
             X = np.ascontiguousarray(X)
-            xdtype = X.dtype
+            xdtype = src_dtype = X.dtype
             Xd = self._torch.from_numpy(X).to(self.device)
             xxd = self._norms(Xd, _x_dtype_code(xdtype), X.shape[0], X.shape[1])
         if W.ndim != 2 or W.shape[1] != Xd.shape[1]:
             raise ValueError("prototype / sample feature mismatch")
         Wd = self._dev_f64(W)
         wwd = self._norms(Wd, _native.F64, W.shape[0], W.shape[1])
-        dist, idx = self._bmu_dev(Xd, xxd, xdtype, Wd, wwd, k, self._round_f32(W, xdtype))
+        dist, idx = self._bmu_dev(Xd, xxd, xdtype, Wd, wwd, k, self._round_f32(W, src_dtype))
         dist, idx = dist.cpu().numpy(), idx.cpu().numpy()
         if k == 1:
             return dist.reshape(-1), idx.reshape(-1)
@@ -464,7 +480,8 @@ class HipBackend(HotPathBackend):
             self._filtered_this_epoch = False
             if self._filter_backoff > 0:
                 self._filter_backoff -= 1
-            dist, idx = self._bmu_dev(self._X, self._xx, self._x_np_dtype, Wd, wwd, 1, rf)
+            Xb, xb_dtype = self._bmu_samples()
+            dist, idx = self._bmu_dev(Xb, self._xx, xb_dtype, Wd, wwd, 1, rf)
         dist, idx = dist.view(-1), idx.view(-1)
         kw = self._exp_similarity_dev(dist, gamma)
         self._last_idx = idx
@@ -533,7 +550,8 @@ class HipBackend(HotPathBackend):
         self._require_loaded()
         Wd, rf = self._as_dev_weights(W)
         wwd = self._norms(Wd, _native.F64, Wd.shape[0], Wd.shape[1])
-        return self._bmu_dev(self._X, self._xx, self._x_np_dtype, Wd, wwd, k, rf)
+        Xb, xb_dtype = self._bmu_samples()
+        return self._bmu_dev(Xb, self._xx, xb_dtype, Wd, wwd, k, rf)
 
     def _sum_dev(self, v):
         torch = self._torch

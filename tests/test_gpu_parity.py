@@ -347,6 +347,30 @@ def test_bf16_storage_matches_oracle_on_rounded_samples(hip, o, N, d, M):
     assert np.array_equal(i2, ri) and np.array_equal(d2, rd)
 
 
+def test_bf16_samples_filtered_search_is_identical_to_exact(o):
+    """bfloat16-resident samples through the filtered search (float32 widened copy for the BMU
+    kernels, bfloat16 rows for the accumulate step) = the all-pairs search = the oracle on the
+    rounded samples."""
+    from dbgsom_amd.backend import HipBackend
+
+    N, d, rows, cols = 7000, 512, 20, 20
+    M = rows * cols
+    X, _ = gi.blobs_f32(N, d, 99)
+    Xr = _bf16_round(X)
+    W = Xr[np.random.default_rng(2).choice(N, M, replace=False)].astype(np.float64)
+    hop = gi.lattice_hops(rows, cols)
+    ex = HipBackend(algorithm="exact").load(X, storage="bf16")
+    fi = HipBackend(algorithm="filtered").load(X, storage="bf16")
+    re_ = ex.epoch(W, hop, 3.0, 1e-3, "compact", True)
+    rf = fi.epoch(W, hop, 3.0, 1e-3, "compact", True)
+    assert fi._planes is not None and fi._X.dtype.is_floating_point and fi._X.element_size() == 2
+    assert np.array_equal(re_.winners, rf.winners) and np.array_equal(re_.distances, rf.distances)
+    assert np.array_equal(re_.new_weights, rf.new_weights)
+    pick = np.random.default_rng(0).choice(N, 1500, replace=False)
+    rd, ri = o.bmu_chain(Xr[pick], W, 1)
+    assert np.array_equal(rf.winners[pick], ri) and np.array_equal(rf.distances[pick], rd)
+
+
 @pytest.mark.parametrize("N,d,rows,cols", [(20000, 784, 16, 16), (5000, 64, 18, 19),
                                             (12345, 128, 17, 17), (9000, 208, 30, 30),
                                             (6000, 48, 23, 23)])
