@@ -46,6 +46,7 @@ SIGNATURES = {
     "dbgsom_bmu_filtered_stage_ms": (_ci, [_vp]),
     "dbgsom_sum_workspace_bytes": (_sz, []),
     "dbgsom_sum_f64": (_ci, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "dbgsom_column_sums": (_ci, [_vp, _ci, _i64, _i64, _i64, _vp, _vp, _vp]),
     "dbgsom_topographic_count": (_ci, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "dbgsom_density_terms": (_ci, [_vp, _i64, _dbl, _vp, _vp]),
     "dbgsom_class_histogram": (_ci, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),

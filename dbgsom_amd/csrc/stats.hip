@@ -89,6 +89,49 @@ static unsigned grid_for(int64_t n) {
     return (unsigned)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
 }
 
+// Column sums in NumPy's own arithmetic for a reduction over axis 0 of a C-ordered array: every
+// column is summed SEQUENTIALLY over the rows, in the array's dtype, no fused multiply-add --
+// np.sum(X, axis=0) and, with `mean`, np.sum((X - mean) ** 2, axis=0) bit for bit (checked against
+// NumPy in tests/test_gpu_parity.py).  One thread per column keeps the order; the loads of CU rows
+// are independent and in flight together, only the adds form the chain.
+template <typename T> __device__ __forceinline__ T add_rn(T a, T b);
+template <> __device__ __forceinline__ float add_rn<float>(float a, float b) { return __fadd_rn(a, b); }
+template <> __device__ __forceinline__ double add_rn<double>(double a, double b) { return __dadd_rn(a, b); }
+template <typename T> __device__ __forceinline__ T mul_rn(T a, T b);
+template <> __device__ __forceinline__ float mul_rn<float>(float a, float b) { return __fmul_rn(a, b); }
+template <> __device__ __forceinline__ double mul_rn<double>(double a, double b) { return __dmul_rn(a, b); }
+
+template <typename T>
+__global__ __launch_bounds__(64) void column_sums_kernel(const T *__restrict__ X, int64_t N, int d,
+                                                         int64_t ld, const T *__restrict__ mean,
+                                                         T *__restrict__ out) {
+    constexpr int CU_ROWS = 32;
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= d) return;
+    const T m = mean ? mean[j] : (T)0;
+    const bool centred = mean != nullptr;
+    T acc = (T)0;
+    const T *p = X + j;
+    int64_t i = 0;
+    for (; i + CU_ROWS <= N; i += CU_ROWS) {
+        T v[CU_ROWS];
+#pragma unroll
+        for (int u = 0; u < CU_ROWS; ++u) v[u] = p[(i + u) * ld];
+#pragma unroll
+        for (int u = 0; u < CU_ROWS; ++u) {
+            T x = v[u];
+            if (centred) { x = add_rn<T>(x, -m); x = mul_rn<T>(x, x); }
+            acc = add_rn<T>(acc, x);
+        }
+    }
+    for (; i < N; ++i) {
+        T x = p[i * ld];
+        if (centred) { x = add_rn<T>(x, -m); x = mul_rn<T>(x, x); }
+        acc = add_rn<T>(acc, x);
+    }
+    out[j] = acc;
+}
+
 }  // namespace dbgsom
 
 using namespace dbgsom;
@@ -145,6 +188,22 @@ int dbgsom_class_histogram(const int64_t *idx_dev, const int32_t *y_dev, int64_t
     hipLaunchKernelGGL(class_hist_kernel, dim3(grid_for(n)), dim3(256), 0, s, idx_dev, y_dev, n,
                        (int)M, (int)n_classes, (unsigned long long *)hist_dev);
     return launch_status("class_hist_kernel");
+}
+
+int dbgsom_column_sums(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                       const void *mean_dev, void *out_dev, void *stream) {
+    DBGSOM_REQUIRE(x_dtype == DBGSOM_F32 || x_dtype == DBGSOM_F64, "float32 / float64 samples only");
+    DBGSOM_REQUIRE(N >= 0 && d >= 1 && d <= 0x7fffffff && ldx >= d && out_dev, "bad arguments");
+    DBGSOM_REQUIRE(N == 0 || X_dev, "null input");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((d + 63) / 64)), block(64);
+    if (x_dtype == DBGSOM_F32)
+        hipLaunchKernelGGL(column_sums_kernel<float>, grid, block, 0, s, (const float *)X_dev, N, (int)d,
+                           ldx, (const float *)mean_dev, (float *)out_dev);
+    else
+        hipLaunchKernelGGL(column_sums_kernel<double>, grid, block, 0, s, (const double *)X_dev, N, (int)d,
+                           ldx, (const double *)mean_dev, (double *)out_dev);
+    return launch_status("column_sums_kernel");
 }
 
 }  // extern "C"

@@ -160,6 +160,15 @@ int dbgsom_sum_f64(const double *v_dev, int64_t n, double *out_dev, void *worksp
 int dbgsom_topographic_count(const int64_t *idx2_dev, int64_t n, const int32_t *xy_dev, int64_t M,
                              uint64_t *count_dev, void *stream);
 
+/* out[j] = sum_i X[i, j] (mean == NULL) or sum_i (X[i, j] - mean[j])^2, each column summed
+ * sequentially over the rows in X's own dtype without fused multiply-add: the arithmetic of
+ * NumPy's axis-0 reductions, so that np.var / np.std of the resident samples -- the total
+ * variance behind the sample kernel (BaseSom.py:363) and the "se" growing threshold
+ * (BaseSom.py:380-383) -- come out bit for bit without a host pass over X.  F32 / F64 only;
+ * out, mean: d elements of X's dtype on the device. */
+int dbgsom_column_sums(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                       const void *mean_dev, void *out_dev, void *stream);
+
 /* out_i = exp(-dist_i^2 / (2 sigma^2)) / (sigma sqrt(2 pi)): the per-sample term of the local
  * density estimate, BaseSom._calculate_node_statistics BaseSom.py:203-206.  Feeding it to
  * dbgsom_accumulate as `kw` yields per-neuron density sums (K) and hit counts (a). */

@@ -321,6 +321,21 @@ def test_device_reductions_f2_f3(hip, o):
     assert np.array_equal(res.class_hist, ref)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("N,d", [(50_000, 100), (1797, 64), (33, 784), (200_000, 7)])
+def test_column_moments_are_numpys_var_and_std_bit_for_bit(hip, N, d, dt):
+    """np.var(X, 0) and np.std(X, 0, ddof=1) -- total variance and the "se" growing threshold of
+    BaseSom._initialize_som (BaseSom.py:363, 380) -- from the resident samples."""
+    rng = np.random.default_rng(N + d)
+    X = (rng.normal(size=(N, d)) * rng.uniform(0.1, 30.0, size=d) + rng.normal(size=d) * 5).astype(dt)
+    hip.load(X)
+    s1, s2, n = hip.column_moments()
+    assert n == N and s1.dtype == dt and s2.dtype == dt
+    assert np.array_equal(s1, np.sum(X, axis=0))
+    assert np.array_equal(np.true_divide(s2, N), np.var(X, axis=0))
+    assert np.array_equal(np.sqrt(np.true_divide(s2, N - 1)), np.std(X, axis=0, ddof=1))
+
+
 def _bf16_round(X):
     import torch
 
