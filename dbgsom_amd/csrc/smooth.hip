@@ -115,17 +115,34 @@ __global__ __launch_bounds__(256) void smooth_gemm_kernel(const double *__restri
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v) acc[u][v] = sd4_t{0.0, 0.0, 0.0, 0.0};
-    for (int j0 = 0; j0 < M; j0 += GK) {
-        __syncthreads();
-        for (int e = t; e < GT * GK; e += 256) {
+    // global -> register -> LDS staging, one k-tile ahead: the loads of tile j0 + GK are in flight
+    // while tile j0 feeds the matrix cores (64 k-tiles of 2 x 1024 values per workgroup; without
+    // the prefetch every tile exposed a full L2/HBM round trip)
+    constexpr int PER = GT * GK / 256;  // 4 elements of each operand tile per thread
+    double gr[PER], cr[PER];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = t + 256 * u;
             const int r = e / GK, k = e % GK;  // G tile: 64 rows x 16 j
             const int gi = i0 + r, gj = j0 + k;
-            gs[r * GS_A + k] = (gi < M && gj < M) ? G[(size_t)gi * M + gj] : 0.0;
+            gr[u] = (gi < M && gj < M) ? G[(size_t)gi * M + gj] : 0.0;
             const int kr = e / GT, cc = e % GT;  // C tile: 16 j x 64 cols
             const int cj = j0 + kr, col = c0 + cc;
-            cs[kr * GS_B + cc] = (cj < M && col < d) ? C[(size_t)cj * d + col] : 0.0;
+            cr[u] = (cj < M && col < d) ? C[(size_t)cj * d + col] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int j0 = 0; j0 < M; j0 += GK) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = t + 256 * u;
+            gs[(e / GK) * GS_A + e % GK] = gr[u];
+            cs[(e / GT) * GS_B + e % GT] = cr[u];
         }
         __syncthreads();
+        if (j0 + GK < M) fetch(j0 + GK);
 #pragma unroll
         for (int ks = 0; ks < GK / 4; ++ks) {
             double a[2], b[2];
