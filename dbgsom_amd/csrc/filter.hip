@@ -36,7 +36,7 @@ constexpr int PREPASS_KTILES = 3;  // k-tiles the seed pre-pass samples (evenly 
 #endif
 #ifndef SWEEP_EXPERIMENT
 #define SWEEP_EXPERIMENT 0  // timing experiments only: 1 no X DMA, 2 no W DMA, 4 no MFMA, 8 no chunk epilogue,
-// 32 contiguous X source addressing, 64 (with 8) products dead
+// 64 (with 8) products dead, 256 in-kernel s_memtime stamps (tools/sweep_stamps.py)
 #endif
 
 // plane rows are padded to whole k-tiles, at least two of them (the sweep's ring runs three tiles
@@ -275,8 +275,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     uint32_t *mask = reinterpret_cast<uint32_t *>(smem + L::OFF_MASK);
     int *misc = reinterpret_cast<int *>(smem + L::OFF_MISC);
 
-#if SWEEP_EXPERIMENT & 1024  // launch cost only: return at once (LDS still allocated)
-    if (N > 0) { if (threadIdx.x == 0) smem[0] = 1; return; }
+#if SWEEP_EXPERIMENT & 256
+    const uint64_t k_start = __builtin_amdgcn_s_memtime();
+    uint64_t k_pro = 0, k_fill = 0, k_loop = 0;
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -287,12 +288,29 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const int nwords = (M + 31) / 32;
 
     auto sample_at = [&](int64_t p) -> int64_t { return order ? (int64_t)order[p] : p; };
+    // Every thread's own loads first (sample indices, then the per-sample constants that hang on
+    // them), BEFORE the first workgroup barrier: with one workgroup per CU nothing else hides the
+    // prologue, and taken one after the other its order -> prev / order -> (s, |x|_1, |x|^2) /
+    // order -> row chains are five or six HBM round trips before the first DMA can go out.
+    const int dr = 16 * wave + (lane >> 2), dcp = lane & 3;  // DMA: wave w loads X rows 16w..16w+15
+    const int64_t xpos = (p0 + dr < N) ? (p0 + dr) : (N - 1);
+    const int64_t i_dr = sample_at(xpos);
+    int64_t i_il[2];
+    double s_i[2], l1_i[2], xx_i[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int64_t p = p0 + wi * 64 + it * 32 + lc;
+        i_il[it] = sample_at(p < N ? p : N - 1);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        s_i[it] = sx[i_il[it]];
+        l1_i[it] = MODE == 0 ? l1x[i_il[it]] : 0.0;
+        xx_i[it] = MODE == 0 ? xx[i_il[it]] : 0.0;
+    }
     int jlo = 0, jhi = -1;
     if constexpr (MODE == 0) {
         for (int w = tid; w < nwords; w += FNT) mask[w] = 0u;
-#if SWEEP_EXPERIMENT & 128
-        if (tid == 0) misc[3] = 0;
-#endif
         if (tid < 128) {
             const int64_t p = p0 + tid;
             int pj = -1;
@@ -375,37 +393,26 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     // per-lane sample constants (2 samples: one per 32-column tile)
     // A_i = |x_i|^2 - thr_i with thr_i = r~(i, seed_i) + 2 eps_i the bound from the seed: the marking
     // test r~_ij <= thr_i only needs A_i, and A_i = s c T - |w_seed|^2 - 2 eps needs no |x_i|^2
-    double s_i[2], eps2_i[2], A_i[2];
+    double eps2_i[2], A_i[2];
     const double l1w_max = summary[0], t_max = summary[1], yy_max = summary[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int il = wi * 64 + it * 32 + lc;
-        const int64_t p = p0 + il;
-        const int64_t i = sample_at(p < N ? p : N - 1);
-        s_i[it] = sx[i];
         if constexpr (MODE == 0) {
-            eps2_i[it] = 2.0 * filter_eps(s_i[it], l1x[i], xx[i], l1w_max, t_max, yy_max, d, PLANES);
+            eps2_i[it] = 2.0 * filter_eps(s_i[it], l1_i[it], xx_i[it], l1w_max, t_max, yy_max, d, PLANES);
             A_i[it] = thr_s[il];
         } else {
             eps2_i[it] = 0.0; A_i[it] = 0.0;
         }
     }
-#if SWEEP_EXPERIMENT & 2048  // launch + prologue loads only
-    if (N > 0) {
-        if (s_i[0] + s_i[1] + eps2_i[0] + eps2_i[1] + A_i[0] + A_i[1] == 12345.0) smem[1] = 1;
-        return;
-    }
-#endif
     double bestv[2] = {INFINITY, INFINITY};  // MODE 1: running arg-min of r~
     int bestj[2] = {0, 0};
 
     // ---- DMA sources: per plane, wave w loads X rows 16w..16w+15 and W rows 16w + 128u ..+15 ----
-    const int dr = 16 * wave + (lane >> 2), dcp = lane & 3;
     const int dc = dcp ^ ((dr >> 2) & 3);  // source chunk for the linear LDS chunk (swizzle)
-    const int64_t xpos = (p0 + dr < N) ? (p0 + dr) : (N - 1);
     const size_t xplane_stride = (size_t)N * dpad;
     const size_t wplane_stride = (size_t)w_rows * dpad;  // w_rows: padded rows of one W plane
-    const int8_t *xsrc = xplanes + (size_t)sample_at(xpos) * dpad + dc * 16;
+    const int8_t *xsrc = xplanes + (size_t)i_dr * dpad + dc * 16;
     // MODE 1 may look at a sample of the k-tiles only (nkt_used of them, evenly spaced): seeds
     // need not be good, only cheap -- see dbgsom_bmu_filtered
     const int nkt_full = dpad / FKT;  // >= 2 (filter_dpad)
@@ -540,6 +547,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     // [read k-step 0 of t + 1] [products of k-step 1].  Every read has 2 JT (1 + .. + NLV)
     // products of the other k-step in front of it, the barrier is the only point the matrix pipe
     // drains.
+#if SWEEP_EXPERIMENT & 256
+    k_pro = __builtin_amdgcn_s_memtime();
+#endif
     const int n_pre = ntile < 3 ? ntile : 3;
     for (int u = 0; u < n_pre; ++u) issue_ops(0, DMA_TILE);
     {   // groups 1 and 2 may stay in flight (group 2 opens a chunk iff nkt == 2)
@@ -548,6 +558,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#if SWEEP_EXPERIMENT & 256
+    k_fill = __builtin_amdgcn_s_memtime();
+#endif
     Frags f0, f1;
     load_frags(0, 0, f0);
     const int dma_slot = wave >= 4 ? 1 : 0;  // product group behind which this wave issues DMAs
@@ -676,9 +689,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
                 uint32_t hit = 0;
-#if SWEEP_EXPERIMENT & 128
-                uint32_t hit2 = 0;  // one bit per (sample, prototype) pair
-#endif
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     double y4[4], c4[4];
@@ -698,9 +708,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                                 if constexpr (PLANES == 3) Tp = Tp * 256.0 + (double)acc[jt][it][2][r];
                                 const bool pass = (A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp;
                                 hit |= (uint32_t)(j < M && pass) << r;
-#if SWEEP_EXPERIMENT & 128
-                                hit2 |= (uint32_t)(j < M && pass) << (2 * r + it);
-#endif
                             } else {
                                 const double T = combine(acc[jt][it][0][r], acc[jt][it][1][r],
                                                          PLANES == 3 ? acc[jt][it][NLV - 1][r] : 0);
@@ -716,9 +723,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                         const int j = jc + jl0 + jt * 32 + (r & 3) + 8 * (r >> 2);
                         if ((hit >> r) & 1u) atomicOr(&mask[j >> 5], 1u << (j & 31));
                     }
-#if SWEEP_EXPERIMENT & 128
-                    atomicAdd(&misc[3], __popc(hit2));
-#endif
                 }
             }
 #pragma unroll
@@ -739,6 +743,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         r_stage = r_next;
     }
 
+#if SWEEP_EXPERIMENT & 256
+    k_loop = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (MODE == 1) {
         // seed = arg-min of r~ over the 2 lane halves and the 4 prototype wavefronts
         __syncthreads();
@@ -796,11 +803,13 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         {   // stamps of waves 0 and 4 behind the list: uint32 at uint16 offset 512 of this row
             unsigned *dbg = reinterpret_cast<unsigned *>(out + 512);
             for (int e = lane; e < 130; e += 64) dbg[e] = wstamps[e] - wstamps[0];
-            if (lane == 0) dbg[130] = (unsigned)(__builtin_amdgcn_s_memtime() - w_start);
+            if (lane == 0) {
+                dbg[130] = (unsigned)(__builtin_amdgcn_s_memtime() - k_start);
+                dbg[131] = (unsigned)(k_pro - k_start);
+                dbg[132] = (unsigned)(k_fill - k_pro);
+                dbg[133] = (unsigned)(k_loop - k_fill);
+            }
         }
-#endif
-#if SWEEP_EXPERIMENT & 128
-        if (lane == 0) ucount[blockIdx.x] = (uint32_t)misc[3];  // pairs instead of list length
 #endif
     }
 }

@@ -37,9 +37,9 @@ nb = (n + 127) // 128
 Mpad = (M + 255) // 256 * 256
 ws = hip._ws["filter"]
 rows_u16 = ws[off: off + nb * Mpad * 2].cpu().numpy().view(np.uint16).reshape(nb, Mpad)
-dbg = np.ascontiguousarray(rows_u16[:, 512: 512 + 262]).view(np.uint32).view(np.int32).astype(np.int64)
+dbg = np.ascontiguousarray(rows_u16[:, 512: 512 + 268]).view(np.uint32).view(np.int32).astype(np.int64)
 total = dbg[:, 130]
-print(f"{name}: kernel time per workgroup (cycles) median {np.median(total):.0f}")
+print(f"{name}: cycles per workgroup median {np.median(total):.0f} = prologue {np.median(dbg[:, 131]):.0f} + ring fill {np.median(dbg[:, 132]):.0f} + tile loop {np.median(dbg[:, 133]):.0f} + list compaction {np.median(total - dbg[:, 131] - dbg[:, 132] - dbg[:, 133]):.0f}")
 for w, nm in ((0, "wave 0 (early DMA issue)"), (1, "wave 4 (late DMA issue)")):
     st = dbg[:, w * 65: w * 65 + 65].reshape(nb, 13, 5)
     dt = np.diff(st, axis=2)
