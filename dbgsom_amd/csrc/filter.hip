@@ -32,10 +32,14 @@ constexpr int FNT = 512;          // threads per sweep workgroup (8 wavefronts)
 constexpr int FSTAGES = 3;
 constexpr int PREPASS_KTILES = 3;  // k-tiles the seed pre-pass samples (evenly spaced)
 #ifndef SUBSET_EXPERIMENT
-#define SUBSET_EXPERIMENT 0  // timing experiments: 1 no X DMA, 2 no W DMA, 4 no MFMA
+// Diagnostic builds of this file (never the shipped library): -DSUBSET_EXPERIMENT=<bits> /
+// -DSWEEP_EXPERIMENT=<bits> switch single resources off to see what a kernel's time is made of,
+// or add s_memtime stamps; run them through DBGSOM_LIB=<that .so> tools/sweep_stage_times.py.
+#define SUBSET_EXPERIMENT 0  // 1 no X DMA, 2 no W DMA, 4 no MFMA, 8 no LDS reads, 16 no barrier,
+// 32 return at once, 64 half occupancy, 128 stamps (tools/subset_stamps.py)
 #endif
 #ifndef SWEEP_EXPERIMENT
-#define SWEEP_EXPERIMENT 0  // timing experiments only: 1 no X DMA, 2 no W DMA, 4 no MFMA, 8 no chunk epilogue,
+#define SWEEP_EXPERIMENT 0  // 4 no MFMA, 8 no chunk epilogue,
 // 64 (with 8) products dead, 256 in-kernel s_memtime stamps (tools/sweep_stamps.py)
 #endif
 
