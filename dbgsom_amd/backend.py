@@ -354,27 +354,46 @@ class HipBackend(HotPathBackend):
             return self._p(self._prev_idx), self._p(self._order)
         return None, None
 
-    def _bmu_filtered_dev(self, Wd, wwd, round_f32):
+    def _make_planes(self, X32):
+        N, d = X32.shape
+        nbytes = self._lib.dbgsom_filter_planes_bytes(N, d)
+        planes = self._torch.empty(nbytes, dtype=self._torch.uint8, device=self.device)
+        _native.call("dbgsom_filter_prepare", self._p(X32), _native.F32, N, d, d, self._p(planes),
+                     nbytes, self._stream())
+        return planes
+
+    def _bmu_filtered_on(self, X32, xxd, planes, Wd, wwd, round_f32, prev_p, order_p, ws_key):
         torch = self._torch
-        N, d = self._X.shape
+        N, d = X32.shape
         M = Wd.shape[0]
-        X32, _ = self._bmu_samples()
-        if self._planes is None:  # digit planes of X: once per resident sample set
-            nbytes = self._lib.dbgsom_filter_planes_bytes(N, d)
-            self._planes = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            _native.call("dbgsom_filter_prepare", self._p(X32), _native.F32, N, d, d,
-                         self._p(self._planes), nbytes, self._stream())
         idx = torch.empty((N, 1), dtype=torch.int64, device=self.device)
         dist = torch.empty((N, 1), dtype=torch.float64, device=self.device)
         need = self._lib.dbgsom_bmu_filtered_workspace_bytes(N, d, M)
-        ws = self._buf("filter", need)
-        prev_p, order_p = self._hint()
+        ws = self._buf(ws_key, need)
         self._timed_call("bmu", "dbgsom_bmu_filtered", self._p(X32), _native.F32, N, d, d,
-                         self._p(self._xx), self._p(self._planes), self._p(Wd), M, self._p(wwd),
+                         self._p(xxd), self._p(planes), self._p(Wd), M, self._p(wwd),
                          prev_p, order_p, int(self.seed_stride), int(self.sweep_planes), round_f32,
                          self._p(idx),
                          self._p(dist), self._p(ws), ws.numel(), self._stream())
         return dist, idx
+
+    def _bmu_filtered_dev(self, Wd, wwd, round_f32):
+        X32, _ = self._bmu_samples()
+        if self._planes is None:  # digit planes of X: once per resident sample set
+            self._planes = self._make_planes(X32)
+        prev_p, order_p = self._hint()
+        self._last_filter_M = Wd.shape[0]
+        return self._bmu_filtered_on(X32, self._xx, self._planes, Wd, wwd, round_f32, prev_p,
+                                     order_p, "filter")
+
+    # queries (predict, post-fit statistics) below this many rows go to the all-pairs kernel: the
+    # digit planes of a one-off X cost a pass over it
+    FILTER_MIN_QUERY_ROWS = 32768
+
+    def _query_filter_applies(self, N, d, M, xdtype, k):
+        return (k == 1 and self.algorithm != "exact" and not isinstance(xdtype, str)
+                and xdtype == np.float32 and d % 16 == 0 and N >= self.FILTER_MIN_QUERY_ROWS
+                and self.FILTER_MIN_PROTOTYPES <= M <= _native.MAX_PROTOTYPES)
 
     def filter_counts(self):
         """Candidate-list length per 128-sample workgroup of the last filtered search."""
@@ -422,7 +441,14 @@ class HipBackend(HotPathBackend):
             raise ValueError("prototype / sample feature mismatch")
         Wd = self._dev_f64(W)
         wwd = self._norms(Wd, _native.F64, W.shape[0], W.shape[1])
-        dist, idx = self._bmu_dev(Xd, xxd, xdtype, Wd, wwd, k, self._round_f32(W, src_dtype))
+        rf = self._round_f32(W, src_dtype)
+        if X is None and k == 1 and self._filter_applies(W.shape[0]):
+            dist, idx = self._bmu_filtered_dev(Wd, wwd, rf)   # resident samples: planes are cached
+        elif X is not None and self._query_filter_applies(X.shape[0], X.shape[1], W.shape[0], xdtype, k):
+            dist, idx = self._bmu_filtered_on(Xd, xxd, self._make_planes(Xd), Wd, wwd, rf, None, None,
+                                              "filter_query")
+        else:
+            dist, idx = self._bmu_dev(Xd, xxd, xdtype, Wd, wwd, k, rf)
         dist, idx = dist.cpu().numpy(), idx.cpu().numpy()
         if k == 1:
             return dist.reshape(-1), idx.reshape(-1)
@@ -550,6 +576,8 @@ class HipBackend(HotPathBackend):
         self._require_loaded()
         Wd, rf = self._as_dev_weights(W)
         wwd = self._norms(Wd, _native.F64, Wd.shape[0], Wd.shape[1])
+        if k == 1 and self._filter_applies(Wd.shape[0]):
+            return self._bmu_filtered_dev(Wd, wwd, rf)
         Xb, xb_dtype = self._bmu_samples()
         return self._bmu_dev(Xb, self._xx, xb_dtype, Wd, wwd, k, rf)
 

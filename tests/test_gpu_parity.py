@@ -428,6 +428,32 @@ def test_filtered_search_is_identical_to_exact(o, N, d, rows, cols):
     assert np.array_equal(i1[pick], ri) and np.array_equal(d1[pick], rd)
 
 
+def test_large_queries_take_the_filtered_search_and_agree_with_the_all_pairs_kernel(o):
+    """predict-style k = 1 queries on samples that are not resident (HipBackend.bmu(W, 1, X)) and
+    post-fit queries on the resident ones go through the filtered search when they are large."""
+    from dbgsom_amd.backend import HipBackend
+
+    N, d, rows, cols = 40_000, 96, 19, 19
+    M = rows * cols
+    X, _ = gi.blobs_f32(N, d, 31)
+    W = X[np.random.default_rng(3).choice(N, M, replace=False)].astype(np.float64) + 0.01
+    auto = HipBackend(algorithm="auto").load(X[:5000])
+    exact = HipBackend(algorithm="exact").load(X[:5000])
+    assert auto._query_filter_applies(N, d, M, X.dtype, 1) and not exact._query_filter_applies(N, d, M, X.dtype, 1)
+    da, ia = auto.bmu(W, 1, X)
+    de, ie = exact.bmu(W, 1, X)
+    assert np.array_equal(ia, ie) and np.array_equal(da, de)
+    pick = np.random.default_rng(0).choice(N, 1000, replace=False)
+    rd, ri = o.bmu_chain(X[pick], W, 1)
+    assert np.array_equal(ia[pick], ri) and np.array_equal(da[pick], rd)
+    # resident samples, digit planes cached by the query itself
+    big = HipBackend(algorithm="auto").load(X)
+    db, ib = big.bmu(W, 1)
+    assert big._planes is not None and np.array_equal(ib, ie) and np.array_equal(db, de)
+    d2, i2 = big.bmu(W, 2)          # k = 2 stays on the all-pairs kernel
+    assert np.array_equal(i2[:, 0], ie)
+
+
 def test_filtered_search_with_ties_and_bad_previous_winners(o):
     """Duplicated prototypes (exact ties -> lowest index) and deliberately wrong previous winners:
     the result must not depend on the quality of the hint."""
