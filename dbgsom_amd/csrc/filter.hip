@@ -567,14 +567,20 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #endif
     Frags f0, f1;
     load_frags(0, 0, f0);
+    // (measured, no effect beyond run-to-run noise: s_setprio for the later-slot wavefronts, slots
+    // mixed across the SIMDs instead of by wavefront half)
     const int dma_slot = wave >= 4 ? 1 : 0;  // product group behind which this wave issues DMAs
 #if SWEEP_EXPERIMENT & 256
-    __shared__ unsigned wstamps[2 * 13 * 5];
+    __shared__ unsigned wstamps[2 * 10 * 5];
     const uint64_t w_start = __builtin_amdgcn_s_memtime();
     const bool stamper = lane == 0 && (wave == 0 || wave == 4);
-#define WSTAMP(k) if (stamper && t >= 16 && t < 29) wstamps[(wave >> 2) * 65 + (t - 16) * 5 + (k)] = (unsigned)__builtin_amdgcn_s_memtime()
+#define WSTAMP(k) if (stamper && t >= 16 && t < 26) wstamps[(wave >> 2) * 50 + (t - 16) * 5 + (k)] = (unsigned)__builtin_amdgcn_s_memtime()
+    __shared__ unsigned estamps[4 * 4];
+    int e_seq = 0;
+#define ESTAMP(k) if (stamper && wave == 0 && e_seq < 4) estamps[e_seq * 4 + (k)] = (unsigned)__builtin_amdgcn_s_memtime()
 #else
 #define WSTAMP(k)
+#define ESTAMP(k)
 #endif
     int r_kt = 0, r_cseq = 0, r_chunk = c0, r_stage = 0;
     for (int t = 0; t < ntile; ++t) {
@@ -643,6 +649,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                 continue;
             }
 #endif
+            ESTAMP(0);
             const int jc = r_chunk * BJ;
             const double *ytab = reinterpret_cast<const double *>(smem + L::OFF_TAB + r_cseq * 2 * L::TAB);
             const double *ctb = ytab + BJ;
@@ -685,6 +692,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                     for (int it = 0; it < 2; ++it) A_i[it] = thr_s[wi * 64 + it * 32 + lc];
                 }
             }
+            ESTAMP(1);
             // all table reads and compares of a 32-prototype tile first (bits), the LDS atomics
             // after them: a possible atomic between two elements pins every later table read
             // behind it and exposes one LDS round trip per element.
@@ -692,7 +700,11 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             // form (6 float64 operations per pair instead of 9); MODE 1 needs r~ itself.
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
-                uint32_t hit = 0;
+                // The 32 prototypes of (wavefront column wj, tile jt) are ONE word of the mask:
+                // bit 4 lh + 8 g + i.  A compare leaves its result as a 64-lane mask in scalar
+                // registers anyway, so the word is put together there (did any sample in lane
+                // half lh pass?) and the wavefront issues a single LDS atomic for it.
+                uint32_t word = 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     double y4[4], c4[4];
@@ -705,13 +717,14 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                     for (int i = 0; i < 4; ++i) {
                         const int r = 4 * g + i;
                         const int j = jc + jl0 + jt * 32 + 8 * g + i;
+                        uint64_t pass = 0;  // lanes with a sample that passes (both tiles OR-ed, no
+                                            // short circuit: a branch per pair costs more than the test)
 #pragma unroll
                         for (int it = 0; it < 2; ++it) {
                             if constexpr (MODE == 0) {
                                 double Tp = (double)acc[jt][it][0][r] * 256.0 + (double)acc[jt][it][1][r];
                                 if constexpr (PLANES == 3) Tp = Tp * 256.0 + (double)acc[jt][it][2][r];
-                                const bool pass = (A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp;
-                                hit |= (uint32_t)(j < M && pass) << r;
+                                pass |= __builtin_amdgcn_ballot_w64((A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp);
                             } else {
                                 const double T = combine(acc[jt][it][0][r], acc[jt][it][1][r],
                                                          PLANES == 3 ? acc[jt][it][NLV - 1][r] : 0);
@@ -719,16 +732,22 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                                 if (j < M && rv < bestv[it]) { bestv[it] = rv; bestj[it] = j * jstride; }
                             }
                         }
+                        if constexpr (MODE == 0) {
+                            const uint64_t b = pass;
+                            word |= (uint32_t)((uint32_t)b != 0u) << (8 * g + i);
+                            word |= (uint32_t)((uint32_t)(b >> 32) != 0u) << (4 + 8 * g + i);
+                        }
                     }
                 }
                 if constexpr (MODE == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int j = jc + jl0 + jt * 32 + (r & 3) + 8 * (r >> 2);
-                        if ((hit >> r) & 1u) atomicOr(&mask[j >> 5], 1u << (j & 31));
+                    const int wbase = jc + wj * 32 * JT + jt * 32;  // multiple of 32
+                    if (wbase < M) {
+                        if (M - wbase < 32) word &= (1u << (M - wbase)) - 1u;  // prototypes >= M: padding
+                        if (word != 0u && lane == 0) atomicOr(&mask[wbase >> 5], word);
                     }
                 }
             }
+            ESTAMP(2);
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
@@ -741,6 +760,10 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             r_chunk = (r_chunk + 1 == nchunk) ? 0 : r_chunk + 1;
             r_cseq = (r_cseq == 2) ? 0 : r_cseq + 1;
             load_frags(r_next, 0, f0);
+            ESTAMP(3);
+#if SWEEP_EXPERIMENT & 256
+            ++e_seq;
+#endif
         } else {
             ++r_kt;
         }
@@ -806,12 +829,13 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #if SWEEP_EXPERIMENT & 256
         {   // stamps of waves 0 and 4 behind the list: uint32 at uint16 offset 512 of this row
             unsigned *dbg = reinterpret_cast<unsigned *>(out + 512);
-            for (int e = lane; e < 130; e += 64) dbg[e] = wstamps[e] - wstamps[0];
+            for (int e = lane; e < 100; e += 64) dbg[e] = wstamps[e] - wstamps[0];
             if (lane == 0) {
                 dbg[130] = (unsigned)(__builtin_amdgcn_s_memtime() - k_start);
                 dbg[131] = (unsigned)(k_pro - k_start);
                 dbg[132] = (unsigned)(k_fill - k_pro);
                 dbg[133] = (unsigned)(k_loop - k_fill);
+                for (int q = 0; q < 16; ++q) dbg[134 + q] = estamps[q] - estamps[(q / 4) * 4];
             }
         }
 #endif

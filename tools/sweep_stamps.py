@@ -37,11 +37,11 @@ nb = (n + 127) // 128
 Mpad = (M + 255) // 256 * 256
 ws = hip._ws["filter"]
 rows_u16 = ws[off: off + nb * Mpad * 2].cpu().numpy().view(np.uint16).reshape(nb, Mpad)
-dbg = np.ascontiguousarray(rows_u16[:, 512: 512 + 268]).view(np.uint32).view(np.int32).astype(np.int64)
+dbg = np.ascontiguousarray(rows_u16[:, 512: 512 + 300]).view(np.uint32).view(np.int32).astype(np.int64)
 total = dbg[:, 130]
 print(f"{name}: cycles per workgroup median {np.median(total):.0f} = prologue {np.median(dbg[:, 131]):.0f} + ring fill {np.median(dbg[:, 132]):.0f} + tile loop {np.median(dbg[:, 133]):.0f} + list compaction {np.median(total - dbg[:, 131] - dbg[:, 132] - dbg[:, 133]):.0f}")
 for w, nm in ((0, "wave 0 (early DMA issue)"), (1, "wave 4 (late DMA issue)")):
-    st = dbg[:, w * 65: w * 65 + 65].reshape(nb, 13, 5)
+    st = dbg[:, w * 50: w * 50 + 50].reshape(nb, 10, 5)
     dt = np.diff(st, axis=2)
     per_tile = st[:, 1:, 0] - st[:, :-1, 0]
     loop = st[:, 1:, 0] - st[:, :-1, 4]
@@ -50,3 +50,8 @@ for w, nm in ((0, "wave 0 (early DMA issue)"), (1, "wave 4 (late DMA issue)")):
           f"p90 {np.percentile(per_tile[ok], 90):.0f}); median [first half {np.median(dt[ok][:, :, 0]):.0f} | dma wait "
           f"{np.median(dt[ok][:, :, 1]):.0f} | barrier {np.median(dt[ok][:, :, 2]):.0f} | second half {np.median(dt[ok][:, :, 3]):.0f}"
           f" | epilogue/loop {np.median(loop[ok]):.0f} (mean {loop[ok].mean():.0f})]")
+
+es = dbg[:, 134:150].reshape(nb, 4, 4)
+for q in range(4):
+    print(f"  chunk epilogue {q} (wave 0): seed-bound part {np.median(es[:, q, 1]):.0f}, compares + marks {np.median(es[:, q, 2] - es[:, q, 1]):.0f}, "
+          f"clear + next fragments {np.median(es[:, q, 3] - es[:, q, 2]):.0f} cycles")
