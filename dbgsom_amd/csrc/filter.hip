@@ -1176,6 +1176,27 @@ struct StageTimer {
     }
 };
 thread_local StageTimer g_timer;
+
+// a second stream for launches that may overlap (per thread, created on first use; if it cannot be
+// created the work simply stays on the caller's stream)
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t forked = nullptr, joined = nullptr;
+    int state = 0;  // 0 untried, 1 ready, -1 unavailable
+    int device = -1;
+    bool ready() {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (state == 0) {
+            device = dev;
+            state = (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&forked, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
+        }
+        return state == 1 && dev == device;  // a thread that moved to another device: no fork
+    }
+};
+thread_local SideStream g_side;
 }  // namespace
 
 extern "C" {
@@ -1298,14 +1319,28 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                            f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
                            (int64_t *)nullptr, 1, (int)f.Mpad, 0);
     g_timer.mark(4, s);
-#define DBGSOM_SUBSET(JTL)                                                                       \
-    hipLaunchKernelGGL(subset_exact_kernel<JTL>, dim3((unsigned)f.nb), dim3(NT), 0, s,              \
+    // the three list-length classes write disjoint samples: they run side by side (classes 1 and 2
+    // on a second stream forked from the caller's), so that the tail of one launch -- a few long
+    // lists on a mostly idle chip -- overlaps the others
+    SideStream &side = g_side;
+    const bool fork = side.ready();
+    hipStream_t s2 = fork ? side.stream : s;
+    if (fork) {
+        DBGSOM_HIP_CHECK(hipEventRecord(side.forked, s));
+        DBGSOM_HIP_CHECK(hipStreamWaitEvent(s2, side.forked, 0));
+    }
+#define DBGSOM_SUBSET(JTL, STREAM)                                                                \
+    hipLaunchKernelGGL(subset_exact_kernel<JTL>, dim3((unsigned)f.nb), dim3(NT), 0, STREAM,         \
                        (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev, \
                        f.ulist, (int)f.Mpad, f.ucount, round_f32, idx_dev, dist_dev)
-    DBGSOM_SUBSET(1);
-    DBGSOM_SUBSET(2);
-    DBGSOM_SUBSET(3);
+    DBGSOM_SUBSET(3, s);
+    DBGSOM_SUBSET(2, s2);
+    DBGSOM_SUBSET(1, s2);
 #undef DBGSOM_SUBSET
+    if (fork) {
+        DBGSOM_HIP_CHECK(hipEventRecord(side.joined, s2));
+        DBGSOM_HIP_CHECK(hipStreamWaitEvent(s, side.joined, 0));
+    }
     g_timer.mark(5, s);
     g_timer.valid = g_timer.enabled;
     return launch_status("filtered bmu kernels");
