@@ -27,8 +27,17 @@ struct AccWs {
     uint32_t *seg_start;  // M + 1
     uint32_t *chunk_pre;  // M + 1      exclusive scan of ceil(count / CH)
     double *slab;         // maxchunks * (d + 2)   [partial S | partial K | partial E]
+    double *gslab;        // M * finalize_groups(M) * (d + 2): second level of the ordered sum
     int64_t nb, maxchunks;
 };
+
+// A small map has few neurons with very many chunk partials each: their ordered sum is split into
+// NG consecutive groups summed side by side (then added in group order) so that it fills the
+// chip; NG depends on M alone, the grouping on the counts alone -> still bitwise reproducible.
+static int finalize_groups(int64_t M) {
+    const int64_t g = 512 / (M > 0 ? M : 1);
+    return (int)(g < 1 ? 1 : (g > 32 ? 32 : g));
+}
 
 static size_t carve(AccWs *w, char *base, int64_t N, int64_t d, int64_t M) {
     const int64_t nb = (N + HS - 1) / HS;
@@ -41,6 +50,7 @@ static size_t carve(AccWs *w, char *base, int64_t N, int64_t d, int64_t M) {
     const size_t o_seg = take((size_t)(M + 1) * 4);
     const size_t o_chunk = take((size_t)(M + 1) * 4);
     const size_t o_slab = take((size_t)maxchunks * (d + 2) * 8);
+    const size_t o_gslab = take((size_t)M * finalize_groups(M) * (d + 2) * 8);
     if (w) {
         w->order = (int32_t *)(base + o_order);
         w->blk = (uint32_t *)(base + o_blk);
@@ -48,6 +58,7 @@ static size_t carve(AccWs *w, char *base, int64_t N, int64_t d, int64_t M) {
         w->seg_start = (uint32_t *)(base + o_seg);
         w->chunk_pre = (uint32_t *)(base + o_chunk);
         w->slab = (double *)(base + o_slab);
+        w->gslab = (double *)(base + o_gslab);
         w->nb = nb;
         w->maxchunks = maxchunks;
     }
@@ -284,9 +295,12 @@ __global__ __launch_bounds__(AT) void segsum_kernel(
 __global__ __launch_bounds__(AT) void finalize_kernel(const double *__restrict__ slab, int d,
                                                       int M, const uint32_t *__restrict__ count,
                                                       const uint32_t *__restrict__ chunk_pre,
+                                                      int NG, double *__restrict__ gslab,
                                                       double *__restrict__ sums) {
-    const int j = blockIdx.x;
-    const uint32_t c0 = chunk_pre[j], c1 = chunk_pre[j + 1];
+    const int j = blockIdx.x, g = blockIdx.y;
+    const uint32_t b0 = chunk_pre[j], b1 = chunk_pre[j + 1];
+    const uint32_t per = (b1 - b0 + NG - 1) / NG;  // chunks per group
+    const uint32_t c0 = min(b1, b0 + g * per), c1 = min(b1, c0 + per);
     double *S = sums + (size_t)j * d;
     double *Kp = sums + (size_t)M * d, *ap = Kp + M, *Ep = ap + M;
     for (int col = threadIdx.x; col < d + 2; col += AT) {
@@ -300,11 +314,28 @@ __global__ __launch_bounds__(AT) void finalize_kernel(const double *__restrict__
             for (int u = 0; u < 8; ++u) s += v[u];
         }
         for (; c < c1; ++c) s += slab[(size_t)c * (d + 2) + col];
+        if (NG > 1) gslab[((size_t)j * NG + g) * (d + 2) + col] = s;
+        else if (col < d) S[col] = s;
+        else if (col == d) Kp[j] = s;
+        else Ep[j] = s;
+    }
+    if (threadIdx.x == 0 && g == 0) ap[j] = (double)count[j];
+}
+
+// second level (NG > 1): the NG group sums of a neuron in group order
+__global__ __launch_bounds__(AT) void finalize_groups_kernel(const double *__restrict__ gslab, int d,
+                                                             int M, int NG,
+                                                             double *__restrict__ sums) {
+    const int j = blockIdx.x;
+    double *S = sums + (size_t)j * d;
+    double *Kp = sums + (size_t)M * d, *Ep = Kp + 2 * (size_t)M;
+    for (int col = threadIdx.x; col < d + 2; col += AT) {
+        double s = 0.0;
+        for (int g = 0; g < NG; ++g) s += gslab[((size_t)j * NG + g) * (d + 2) + col];
         if (col < d) S[col] = s;
         else if (col == d) Kp[j] = s;
         else Ep[j] = s;
     }
-    if (threadIdx.x == 0) ap[j] = (double)count[j];
 }
 
 // Stable bucket order of the samples by winner, on its own (the filtered BMU search visits the
@@ -383,8 +414,12 @@ int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t 
         if (al16 && d % 8 == 0) DBGSOM_SEGSUM(bf16_t, 8); else DBGSOM_SEGSUM(bf16_t, 1);
     }
 #undef DBGSOM_SEGSUM
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)M), dim3(AT), 0, s, w.slab, di, Mi, w.count,
-                       w.chunk_pre, sums);
+    const int NG = finalize_groups(M);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)M, (unsigned)NG), dim3(AT), 0, s, w.slab, di, Mi,
+                       w.count, w.chunk_pre, NG, w.gslab, sums);
+    if (NG > 1)
+        hipLaunchKernelGGL(finalize_groups_kernel, dim3((unsigned)M), dim3(AT), 0, s, w.gslab, di, Mi, NG,
+                           sums);
     return launch_status("accumulate kernels");
 }
 

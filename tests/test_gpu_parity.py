@@ -43,6 +43,12 @@ SHAPES = [
     (2049, 130, 257, np.float32),
     (513, 784, 140, np.float32),
     (300, 33, 1030, np.float64),
+    # small maps on the LDS-DMA kernel: 32- and 64-wide prototype chunks
+    (1500, 64, 4, np.float32),
+    (1500, 64, 31, np.float32),
+    (1000, 784, 33, np.float32),
+    (1000, 48, 64, np.float32),
+    (700, 128, 65, np.float32),
 ]
 
 
