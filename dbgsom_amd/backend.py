@@ -186,7 +186,7 @@ class HipBackend(HotPathBackend):
     name = "hip"
 
     # the filtered search pays off once the all-pairs float64 work is large
-    FILTER_MIN_PROTOTYPES = 256
+    FILTER_MIN_PROTOTYPES = 129   # at or below 128 one chunk of the all-pairs kernel is cheaper (measured)
     # "auto": when the candidate lists of a filtered epoch average more than this many
     # prototypes per 128-sample workgroup (near-duplicate prototypes, e.g. a collapsed map) the
     # exact all-pairs kernel is cheaper: use it for the next FILTER_BACKOFF epochs, then re-probe

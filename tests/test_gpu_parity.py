@@ -394,7 +394,7 @@ def test_bf16_samples_filtered_search_is_identical_to_exact(o):
 
 @pytest.mark.parametrize("N,d,rows,cols", [(20000, 784, 16, 16), (5000, 64, 18, 19),
                                             (12345, 128, 17, 17), (9000, 208, 30, 30),
-                                            (6000, 48, 23, 23)])
+                                            (6000, 48, 23, 23), (8000, 96, 10, 13)])
 def test_filtered_search_is_identical_to_exact(o, N, d, rows, cols):
     """The int8-MFMA filter + exact re-evaluation must reproduce the all-pairs float64 search bit
     for bit, over several epochs of a moving map (the filter uses the previous epoch's winners)."""
