@@ -149,7 +149,7 @@ __global__ __launch_bounds__(AT) void scatter_kernel(const int64_t *__restrict__
                                                      const uint32_t *__restrict__ seg_start,
                                                      int32_t *__restrict__ order) {
     extern __shared__ uint32_t cnt[];  // M running write positions of this workgroup
-    __shared__ int keys[AT];
+    __shared__ __attribute__((aligned(16))) int keys[AT];
     const uint32_t *off = blk + (size_t)blockIdx.x * M;
     for (int j = threadIdx.x; j < M; j += AT) cnt[j] = seg_start[j] + off[j];
     const int64_t base = (int64_t)blockIdx.x * HS;
@@ -166,10 +166,14 @@ __global__ __launch_bounds__(AT) void scatter_kernel(const int64_t *__restrict__
         __syncthreads();
         int lower = 0, higher = 0;
         if (key >= 0) {
-            for (int u = 0; u < AT; ++u) {
-                const int ku = keys[u];
-                lower += (ku == key && u < t);
-                higher += (ku == key && u > t);
+            for (int u = 0; u < AT; u += 4) {  // four keys per LDS read (the reads were the cost)
+                const int4 k4 = *reinterpret_cast<const int4 *>(&keys[u]);
+                const int kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lower += (kk[e] == key && u + e < t);
+                    higher += (kk[e] == key && u + e > t);
+                }
             }
             order[cnt[key] + lower] = (int32_t)i;
         }
