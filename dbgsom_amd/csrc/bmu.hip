@@ -325,7 +325,7 @@ int launch_bmu(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx, co
         const char *e = getenv("DBGSOM_BMU_PATH");  // "generic" forces the register-staged kernel
         return e && e[0] == 'g';
     }();
-    if (!force_generic && bmu_dma_usable(X, x_dtype, d, ldx, W))
+    if (!force_generic && bmu_dma_usable(X, x_dtype, d, ldx, W, M))
         return launch_bmu_dma(X, x_dtype, N, d, ldx, xx, W, M, ww, k, round_f32, idx, dist, s);
     const size_t xe = dtype_size(x_dtype);
     const int xvec = is_aligned(X, 16) && ((ldx * xe) % 16 == 0);

@@ -59,6 +59,6 @@ struct Best {
 int launch_bmu_dma(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx, const double *xx,
                    const double *W, int64_t M, const double *ww, int k, int round_f32,
                    int64_t *idx, double *dist, hipStream_t s);
-bool bmu_dma_usable(const void *X, int x_dtype, int64_t d, int64_t ldx, const void *W);
+bool bmu_dma_usable(const void *X, int x_dtype, int64_t d, int64_t ldx, const void *W, int64_t M);
 
 }  // namespace dbgsom

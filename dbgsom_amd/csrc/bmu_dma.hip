@@ -14,6 +14,8 @@
 //   X tile  : f32: 128 rows x 64 B, chunk c at c ^ ((r >> 1) & 3) (2-way on ds_read_b32, the
 //             best a 64-B row allows); f64: laid out like W
 // float32 samples stay float32 in LDS and are widened on the fragment read (exact).
+#include <stdlib.h>
+
 #include "bmu_common.h"
 
 namespace dbgsom {
@@ -260,12 +262,27 @@ __global__ __launch_bounds__(NT, 2) void bmu_dma_kernel(
     }
 }
 
-bool bmu_dma_usable(const void *X, int x_dtype, int64_t d, int64_t ldx, const void *W) {
-    // float64 samples would need 3 x 32 KB of LDS (one workgroup per CU): they take the
-    // register-staged kernel
-    if (x_dtype != DBGSOM_F32) return false;
+// prototype chunk width (16-prototype tiles per wavefront) with the least padded work.  Measured
+// cost of one chunk pass over the samples relative to the 32-wide one: float32 samples
+// 1 : 1.74 : 3.33 (N = 1e6, d = 784: 0.93 / 1.62 / 3.10 ms); float64 samples 1 : 1.66 and no
+// 128-wide form here (X tile 16 KB + W tile 16 KB = one workgroup per CU: the register-staged
+// kernel is faster, 3.6 on this scale per 128 prototypes).  0 = take the register-staged kernel.
+static int dma_chunk_tiles(int x_dtype, int64_t M) {
+    const double n1 = (double)((M + 31) / 32), n2 = (double)((M + 63) / 64), n4 = (double)((M + 127) / 128);
+    if (x_dtype == DBGSOM_F32) {
+        const double c1 = 1.00 * n1, c2 = 1.74 * n2, c4 = 3.33 * n4;
+        return (c4 <= c2 && c4 <= c1) ? 4 : (c2 <= c1 ? 2 : 1);
+    }
+    const double c1 = 1.00 * n1, c2 = 1.66 * n2, cg = 3.6 * n4;
+    if (cg <= c1 && cg <= c2) return 0;
+    return c2 <= c1 ? 2 : 1;
+}
+
+bool bmu_dma_usable(const void *X, int x_dtype, int64_t d, int64_t ldx, const void *W, int64_t M) {
+    if (x_dtype != DBGSOM_F32 && x_dtype != DBGSOM_F64) return false;
     const size_t xe = dtype_size(x_dtype);
-    return d % KT == 0 && is_aligned(X, 16) && (ldx * xe) % 16 == 0 && is_aligned(W, 16);
+    return d % KT == 0 && is_aligned(X, 16) && (ldx * xe) % 16 == 0 && is_aligned(W, 16) &&
+           dma_chunk_tiles(x_dtype, M) != 0;
 }
 
 int launch_bmu_dma(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx, const double *xx,
@@ -276,18 +293,18 @@ int launch_bmu_dma(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx
 #define DBGSOM_DMA_LAUNCH(XT, KK, JTW)                                                            \
     hipLaunchKernelGGL((bmu_dma_kernel<XT, KK, JTW>), grid, block, 0, s, (const XT *)X, N, (int)d, \
                        ldx, xx, W, (int)M, ww, round_f32, idx, dist)
-    // chunk width with the least padded work; measured cost of one chunk pass over the samples,
-    // relative to the 32-wide one: 1 : 1.74 : 3.33 (N = 1e6, d = 784: 0.93 / 1.62 / 3.10 ms)
-    const double c1 = 1.00 * (double)((M + 31) / 32), c2 = 1.74 * (double)((M + 63) / 64),
-                 c4 = 3.33 * (double)((M + 127) / 128);
-    const int jtw = (c4 <= c2 && c4 <= c1) ? 4 : (c2 <= c1 ? 2 : 1);
+    const int jtw = dma_chunk_tiles(x_dtype, M);
 #define DBGSOM_DMA_WIDTH(XT, KK)                                                                  \
     do {                                                                                          \
         if (jtw == 1) DBGSOM_DMA_LAUNCH(XT, KK, 1);                                               \
         else if (jtw == 2) DBGSOM_DMA_LAUNCH(XT, KK, 2);                                          \
         else DBGSOM_DMA_LAUNCH(XT, KK, 4);                                                        \
     } while (0)
-    if (k == 1) DBGSOM_DMA_WIDTH(float, 1); else DBGSOM_DMA_WIDTH(float, 2);
+    if (x_dtype == DBGSOM_F32) {
+        if (k == 1) DBGSOM_DMA_WIDTH(float, 1); else DBGSOM_DMA_WIDTH(float, 2);
+    } else {
+        if (k == 1) DBGSOM_DMA_WIDTH(double, 1); else DBGSOM_DMA_WIDTH(double, 2);
+    }
 #undef DBGSOM_DMA_WIDTH
 #undef DBGSOM_DMA_LAUNCH
     return launch_status("bmu_dma_kernel");
