@@ -277,6 +277,29 @@ class HipBackend(HotPathBackend):
         a = np.ascontiguousarray(a, dtype=np.float64)
         return self._torch.from_numpy(a).to(self.device)
 
+    # Feature padding.  The LDS-DMA kernels and the filtered search want rows of a multiple of 16
+    # features; samples and prototypes are zero-padded to that on their way to the device.  Zeros
+    # change nothing, bit for bit: every dot product and norm is a sequential fma chain, and
+    # fma(0, 0, acc) == acc; sums, centres and new prototypes of the extra columns are zeros.
+    @staticmethod
+    def _padded(d):
+        return (int(d) + 15) // 16 * 16
+
+    def _pad_cols(self, t, dp):
+        d = t.shape[1]
+        if d == dp:
+            return t.contiguous()
+        out = self._torch.zeros((t.shape[0], dp), dtype=t.dtype, device=t.device)
+        out[:, :d] = t
+        return out
+
+    def _dev_weights(self, W):
+        """NumPy (M, d) prototypes -> float64 device tensor (M, padded d)."""
+        Wd = self._dev_f64(W)
+        if Wd.dim() != 2:
+            raise ValueError("prototypes must be a 2-D array")
+        return self._pad_cols(Wd, self._padded(Wd.shape[1]))
+
     def _norms(self, t, dtype_code, rows, d):
         out = self._torch.empty(rows, dtype=self._torch.float64, device=self.device)
         _native.call("dbgsom_row_sqnorms", self._p(t), dtype_code, rows, d, d, self._p(out),
@@ -303,18 +326,15 @@ class HipBackend(HotPathBackend):
             return self.load_device(Xd.to(self._torch.bfloat16))
         if storage not in (None, "native"):
             raise ValueError("storage must be None or 'bf16'")
-        self._x_np_dtype = X.dtype
-        self._X = Xd
-        self._xx = self._norms(self._X, code, X.shape[0], X.shape[1])
-        self._reset_filter_state()
-        return self
+        return self.load_device(Xd)
 
     def load_device(self, X_dev):
         """Adopt samples that already live in HBM (bench: generated on the device)."""
         torch = self._torch
         if X_dev.dtype not in (torch.float32, torch.float64, torch.bfloat16) or X_dev.dim() != 2:
             raise ValueError("X_dev must be a 2-D float32/float64/bfloat16 tensor")
-        X_dev = X_dev.contiguous()
+        self._d = int(X_dev.shape[1])
+        X_dev = self._pad_cols(X_dev, self._padded(self._d))  # (N, padded d), zeros behind column d
         self._x_np_dtype = {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64),
                             torch.bfloat16: "bf16"}[X_dev.dtype]
         self._X = X_dev
@@ -344,7 +364,6 @@ class HipBackend(HotPathBackend):
             return False
         return (self.algorithm != "exact"
                 and (isinstance(self._x_np_dtype, str) or self._x_np_dtype == np.float32)
-                and self._X.shape[1] % 16 == 0
                 and self.FILTER_MIN_PROTOTYPES <= M <= _native.MAX_PROTOTYPES)
 
     def _hint(self):
@@ -435,16 +454,19 @@ class HipBackend(HotPathBackend):
         else:
             X = np.ascontiguousarray(X)
             xdtype = src_dtype = X.dtype
+            if X.ndim != 2 or W.ndim != 2 or W.shape[1] != X.shape[1]:
+                raise ValueError("prototype / sample feature mismatch")
             Xd = self._torch.from_numpy(X).to(self.device)
-            xxd = self._norms(Xd, _x_dtype_code(xdtype), X.shape[0], X.shape[1])
-        if W.ndim != 2 or W.shape[1] != Xd.shape[1]:
+            Xd = self._pad_cols(Xd, self._padded(X.shape[1]))
+            xxd = self._norms(Xd, _x_dtype_code(xdtype), Xd.shape[0], Xd.shape[1])
+        if W.ndim != 2 or self._padded(W.shape[1]) != Xd.shape[1] or (X is None and W.shape[1] != self._d):
             raise ValueError("prototype / sample feature mismatch")
-        Wd = self._dev_f64(W)
-        wwd = self._norms(Wd, _native.F64, W.shape[0], W.shape[1])
+        Wd = self._dev_weights(W)
+        wwd = self._norms(Wd, _native.F64, Wd.shape[0], Wd.shape[1])
         rf = self._round_f32(W, src_dtype)
         if X is None and k == 1 and self._filter_applies(W.shape[0]):
             dist, idx = self._bmu_filtered_dev(Wd, wwd, rf)   # resident samples: planes are cached
-        elif X is not None and self._query_filter_applies(X.shape[0], X.shape[1], W.shape[0], xdtype, k):
+        elif X is not None and self._query_filter_applies(Xd.shape[0], Xd.shape[1], W.shape[0], xdtype, k):
             dist, idx = self._bmu_filtered_on(Xd, xxd, self._make_planes(Xd), Wd, wwd, rf, None, None,
                                               "filter_query")
         else:
@@ -486,12 +508,22 @@ class HipBackend(HotPathBackend):
     def _as_dev_weights(self, W):
         """(device float64 tensor, round_f32 flag) from a NumPy array or a device tensor that a
         previous epoch left in HBM."""
+        dp = self._X.shape[1]
         if self._torch.is_tensor(W):
-            if W.dtype != self._torch.float64 or W.device != self.device or not W.is_contiguous():
-                raise ValueError("device weights must be a contiguous float64 tensor on the backend's GPU")
-            return W, 0
+            if W.dtype != self._torch.float64 or W.device != self.device or W.dim() != 2:
+                raise ValueError("device weights must be a float64 matrix on the backend's GPU")
+            if W.shape[1] == dp and W.is_contiguous():
+                return W, 0
+            if W.shape[1] == self._d and W.stride(1) == 1 and W.stride(0) == dp:
+                # the (M, d) view of a padded (M, dp) result that a previous epoch handed out
+                return W.as_strided((W.shape[0], dp), (dp, 1), W.storage_offset()), 0
+            if W.shape[1] == self._d:
+                return self._pad_cols(W, dp), 0
+            raise ValueError("device weights do not match the resident samples' feature count")
         W = np.asarray(W)
-        return self._dev_f64(W), self._round_f32(W, self._x_np_dtype)
+        if W.ndim != 2 or W.shape[1] != self._d:
+            raise ValueError("prototype / sample feature mismatch")
+        return self._dev_weights(W), self._round_f32(W, self._x_np_dtype)
 
     def _local_sums(self, W, gamma, want_assignments):
         self._require_loaded()
@@ -523,7 +555,7 @@ class HipBackend(HotPathBackend):
     def _sums_from(self, W, sample_weights, winners, distances):
         self._require_loaded()
         torch = self._torch
-        self._W_dev = self._dev_f64(W)
+        self._W_dev = self._dev_weights(W)
         idx = torch.from_numpy(np.ascontiguousarray(winners, dtype=np.int64)).to(self.device)
         kw = self._dev_f64(sample_weights)
         dist = self._dev_f64(distances)
@@ -599,7 +631,7 @@ class HipBackend(HotPathBackend):
         s2 = torch.empty_like(s1)
         _native.call("dbgsom_column_sums", self._p(self._X), code, N, d, d, self._p(mean),
                      self._p(s2), self._stream())
-        return s1.cpu().numpy(), s2.cpu().numpy(), N
+        return s1.cpu().numpy()[:self._d], s2.cpu().numpy()[:self._d], N
 
     def _sum_dev(self, v):
         torch = self._torch
@@ -658,11 +690,8 @@ class HipBackend(HotPathBackend):
 
     def _smooth(self, sums, W, hop, sigma, layout, keep_on_device=False):
         torch = self._torch
-        if torch.is_tensor(W):
-            M, d = W.shape
-        else:
-            W = np.asarray(W)
-            M, d = W.shape
+        M = W.shape[0] if torch.is_tensor(W) else np.asarray(W).shape[0]
+        d = self._X.shape[1]  # padded feature count: what every device array carries
         Wd = getattr(self, "_W_dev", None)
         if Wd is None or tuple(Wd.shape) != (M, d):
             Wd, _ = self._as_dev_weights(W)
@@ -686,7 +715,8 @@ class HipBackend(HotPathBackend):
         if has_status:
             host[3 * M + 1:].view(torch.int32)[:1].copy_(self._ws["status"][:4].view(torch.int32),
                                                          non_blocking=True)
-        Wout = Wn if keep_on_device else Wn.to("cpu", non_blocking=False).numpy()
+        Wv = Wn if d == self._d else Wn[:, :self._d]  # (M, d) view: the padded columns are zeros
+        Wout = Wv if keep_on_device else Wv.to("cpu", non_blocking=False).numpy()
         torch.cuda.current_stream(self.device).synchronize()
         tail = host.numpy()
         if has_status and int(host[3 * M + 1:].view(torch.int32)[0]):

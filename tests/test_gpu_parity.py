@@ -434,6 +434,43 @@ def test_filtered_search_is_identical_to_exact(o, N, d, rows, cols):
     assert np.array_equal(i1[pick], ri) and np.array_equal(d1[pick], rd)
 
 
+@pytest.mark.parametrize("N,d,rows,cols,algo", [(20_000, 100, 12, 13, "filtered"), (3000, 13, 3, 3, "auto"),
+                                                 (9000, 50, 16, 17, "auto"), (2000, 17, 2, 2, "exact")])
+def test_feature_counts_that_are_not_multiples_of_16_take_the_fast_paths_unchanged(o, N, d, rows, cols, algo):
+    """Samples and prototypes are zero-padded to 16-feature multiples on their way to the device
+    (LDS-DMA kernels, filtered search): zeros change no fma chain, results stay those of the
+    oracle on the unpadded data, bit for bit; shapes that come back are the caller's."""
+    from dbgsom_amd.backend import HipBackend
+
+    M = rows * cols
+    X, _ = gi.blobs_f32(N, d, 1000 + d)
+    W = X[np.random.default_rng(4).choice(N, M, replace=False)].astype(np.float64) + 0.001
+    hop = gi.lattice_hops(rows, cols)
+    be = HipBackend(algorithm=algo).load(X)
+    assert be._X.shape[1] % 16 == 0 and be._d == d
+    res = be.epoch(W, hop, 1.5, 1e-3, "compact", True)
+    oo = o.epoch(X, W, hop, 1.5, np.float64(1e3), "compact", "chain")
+    assert res.new_weights.shape == (M, d)
+    assert np.array_equal(res.winners, oo.winners) and np.array_equal(res.distances, oo.distances)
+    np.testing.assert_allclose(res.new_weights, oo.new_weights, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(res.errors, oo.errors, rtol=1e-12)
+    assert abs(res.change_total - oo.change_total) <= 1e-10 * max(1.0, abs(oo.change_total))
+    # device-resident chaining hands out (M, d) views and takes them back
+    r1 = be.epoch(W, hop, 1.5, 1e-3, "compact", False, keep_on_device=True)
+    assert tuple(r1.new_weights_dev.shape) == (M, d)
+    r2 = be.epoch(r1.new_weights_dev, hop, 1.2, 1e-3, "compact", False)
+    o2 = o.epoch(X, oo.new_weights, hop, 1.2, np.float64(1e3), "compact", "chain")
+    np.testing.assert_allclose(r2.new_weights, o2.new_weights, rtol=1e-9, atol=1e-12)
+    # queries on other samples, k = 1 and 2
+    Xq = X[:777] * 1.25
+    for k in (1, 2):
+        dq, iq = be.bmu(W, k, Xq)
+        rd, ri = o.bmu_chain(Xq, W, k)
+        assert np.array_equal(iq, ri) and np.array_equal(dq, rd)
+    s1, s2, n = be.column_moments()
+    assert s1.shape == (d,) and np.array_equal(np.true_divide(s2, N), np.var(X, axis=0))
+
+
 def test_large_queries_take_the_filtered_search_and_agree_with_the_all_pairs_kernel(o):
     """predict-style k = 1 queries on samples that are not resident (HipBackend.bmu(W, 1, X)) and
     post-fit queries on the resident ones go through the filtered search when they are large."""
