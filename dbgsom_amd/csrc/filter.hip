@@ -30,7 +30,8 @@ constexpr double FQ = 8323072.0;  // 127 * 2^16
 constexpr int FKT = 64;           // bytes (= features) per plane row per LDS stage
 constexpr int FNT = 512;          // threads per sweep workgroup (8 wavefronts)
 constexpr int FSTAGES = 3;
-constexpr int PREPASS_KTILES = 3;  // k-tiles the seed pre-pass samples (evenly spaced)
+constexpr int PREPASS_KTILES = 3;  // k-tiles the seed pre-pass samples (tile_select_kernel picks them)
+constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
 #ifndef SUBSET_EXPERIMENT
 // Diagnostic builds of this file (never the shipped library): -DSUBSET_EXPERIMENT=<bits> /
 // -DSWEEP_EXPERIMENT=<bits> switch single resources off to see what a kernel's time is made of,
@@ -89,6 +90,77 @@ __global__ __launch_bounds__(256) void slice_rows_kernel(const T *__restrict__ A
     }
 }
 
+// Which k-tiles (64 features each) the seed pre-pass looks at: the nkt_used tiles in which the
+// prototypes differ most, score = sum over the tile's features of the variance across prototypes
+// (the tile's share of the expected squared distance between two prototypes).  On isotropic data
+// every choice is as good; on data whose information sits in a few feature ranges (images with
+// constant borders, one-hot blocks) evenly spaced tiles can miss it and the seeds degrade to
+// noise -- still exact, but with candidate lists as long as the map.
+constexpr int TS_RB = 32;  // row blocks of the two-stage column sums below
+__global__ __launch_bounds__(256) void tile_partial_kernel(const double *__restrict__ W, int M, int d,
+                                                           int dpad, double *__restrict__ part) {
+    // part[rb][0][k] = sum_j w_jk, part[rb][1][k] = sum_j w_jk^2 over the rows of block rb
+    __shared__ double s1[256], s2[256];
+    const int kt = blockIdx.x, rb = blockIdx.y, f = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int k = kt * FKT + f;
+    const int per = (M + TS_RB - 1) / TS_RB, j0 = rb * per, j1 = min(M, j0 + per);
+    double a = 0.0, b = 0.0;
+    if (k < d)
+        for (int j = j0 + g; j < j1; j += 4) {
+            const double v = W[(size_t)j * d + k];
+            a += v;
+            b += v * v;
+        }
+    s1[threadIdx.x] = a;
+    s2[threadIdx.x] = b;
+    __syncthreads();
+    if (g == 0) {
+        part[((size_t)rb * 2 + 0) * dpad + k] = (s1[f] + s1[f + 64]) + (s1[f + 128] + s1[f + 192]);
+        part[((size_t)rb * 2 + 1) * dpad + k] = (s2[f] + s2[f + 64]) + (s2[f + 128] + s2[f + 192]);
+    }
+}
+
+__global__ __launch_bounds__(64) void tile_score_kernel(const double *__restrict__ part, int M, int dpad,
+                                                        double *__restrict__ score) {
+    const int kt = blockIdx.x, k = kt * FKT + threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int rb = 0; rb < TS_RB; ++rb) {
+        a += part[((size_t)rb * 2 + 0) * dpad + k];
+        b += part[((size_t)rb * 2 + 1) * dpad + k];
+    }
+    double var = b - a * a / (double)M;  // M x variance of feature k over the prototypes
+    var = var > 0.0 ? var : 0.0;
+    for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
+    if (threadIdx.x == 0) score[kt] = var;
+}
+
+// kt_sel[0 .. nkt_used) = the nkt_used best tiles, ascending (ties: lower tile first); one wavefront
+__global__ __launch_bounds__(64) void tile_select_kernel(const double *__restrict__ score, int nkt,
+                                                         int nkt_used, int32_t *__restrict__ kt_sel) {
+    __shared__ int taken[SW_MAX_KT];
+    const int lane = threadIdx.x;
+    for (int t = lane; t < nkt; t += 64) taken[t] = 0;
+    __syncthreads();
+    for (int u = 0; u < nkt_used; ++u) {
+        double best = -1.0;
+        int bt = 0x7fffffff;
+        for (int t = lane; t < nkt; t += 64)
+            if (!taken[t] && (score[t] > best)) { best = score[t]; bt = t; }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 64);
+            const int ot = __shfl_xor(bt, off, 64);
+            if (ob > best || (ob == best && ot < bt)) { best = ob; bt = ot; }
+        }
+        if (lane == 0) taken[bt] = 1;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        int u = 0;
+        for (int t = 0; t < nkt; ++t)
+            if (taken[t]) kt_sel[u++] = t;
+    }
+}
+
 // The prototypes' digit planes in the order the sweep's DMA wants them: int8 [3][dpad / 64][rows_pad]
 // [64], i.e. k-tile-major, so that the 64-byte pieces of 16 consecutive rows are ONE contiguous
 // KiB (whole 128-byte lines per DMA instruction instead of 16 half lines), with the 16-byte
@@ -98,6 +170,7 @@ __global__ __launch_bounds__(256) void slice_rows_kernel(const T *__restrict__ A
 __global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__restrict__ W, int M, int d,
                                                             int dpad, int Mpad, int stride,
                                                             int Msubpad, int nkt_used,
+                                                            const int32_t *__restrict__ kt_sel,
                                                             int8_t *__restrict__ wt,
                                                             int8_t *__restrict__ wt_sub,
                                                             double *__restrict__ scale,
@@ -123,10 +196,9 @@ __global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__rest
     const bool in_sub = (row % stride) == 0;
     const int q = row / stride;
     if (in_sub) {  // |w|^2 over the k-tiles the seed pre-pass looks at (prepass_tile below)
-        const int nkt_full = dpad / FKT;
         double p2 = 0.0;
         for (int u = 0; u < nkt_used; ++u) {
-            const int k = ((u * nkt_full) / nkt_used) * FKT + lane;
+            const int k = (kt_sel ? kt_sel[u] : u) * FKT + lane;  // no selection: all tiles
             if (k < d) p2 += a[k] * a[k];
         }
         for (int off = 32; off > 0; off >>= 1) p2 += __shfl_xor(p2, off, 64);
@@ -269,7 +341,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const double *__restrict__ craw, const double *__restrict__ summary, int M,
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount,
-    int64_t *__restrict__ seed, int jstride, int w_rows, int nkt_used) {
+    int64_t *__restrict__ seed, int jstride, int w_rows, int nkt_used,
+    const int32_t *__restrict__ kt_sel) {
     using L = SweepLds<PLANES, JT>;
     constexpr int NPL = PLANES, NLV = PLANES, BJ = L::BJ;
     constexpr int DMA_TILE = NPL * (1 + JT);  // DMA instructions per wave per tile
@@ -417,11 +490,11 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const size_t xplane_stride = (size_t)N * dpad;
     const size_t wplane_stride = (size_t)w_rows * dpad;  // w_rows: padded rows of one W plane
     const int8_t *xsrc = xplanes + (size_t)i_dr * dpad + dc * 16;
-    // MODE 1 may look at a sample of the k-tiles only (nkt_used of them, evenly spaced): seeds
-    // need not be good, only cheap -- see dbgsom_bmu_filtered
+    // MODE 1 may look at a sample of the k-tiles only (the nkt_used tiles of kt_sel): seeds need
+    // not be good, only cheap -- see dbgsom_bmu_filtered
     const int nkt_full = dpad / FKT;  // >= 2 (filter_dpad)
     const int nkt = (MODE == 1 && nkt_used >= 2 && nkt_used < nkt_full) ? nkt_used : nkt_full;
-    auto tile_of = [&](int kt) { return MODE == 1 ? (kt * nkt_full) / nkt : kt; };
+    auto tile_of = [&](int kt) { return (MODE == 1 && nkt < nkt_full) ? (int)kt_sel[kt] : kt; };
     const int nchunk = (M + BJ - 1) / BJ;
     const int ntile = nkt * nchunk;
     const int c0 = jlo / BJ;  // the sweep starts at the chunk holding the seeds
@@ -1113,6 +1186,9 @@ struct FilterWs {
     int8_t *wt, *wt_sub;   // k-tile-major digit planes of the prototypes / of the pre-pass subset
     double *wscale, *wl1;  // M each
     double *ctab, *yypad, *ctab_sub, *yy_sub, *ictab, *yctab, *yy_part, *summary;
+    double *tile_score;  // dpad / 64
+    double *tile_part;   // TS_RB x 2 x dpad
+    int32_t *kt_sel;     // SW_MAX_KT
     uint16_t *ulist;
     uint32_t *ucount;
     int64_t *seed;     // N   arg-min of the coarse pre-pass (when the caller has no previous winners)
@@ -1129,6 +1205,8 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t o0 = take((size_t)Mpad * 8), o1 = take((size_t)Mpad * 8), o2 = take(64);
     const size_t o8 = take((size_t)Mpad * 8), o9 = take((size_t)Mpad * 8);
     const size_t o10 = take((size_t)Mpad * 8), o11 = take((size_t)Mpad * 8), o12 = take((size_t)Mpad * 8);
+    const size_t o13 = take((size_t)(dpad / FKT) * 8), o14 = take((size_t)SW_MAX_KT * 4);
+    const size_t o15 = take((size_t)TS_RB * 2 * dpad * 8);
     const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
     const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
@@ -1139,6 +1217,8 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
         f->ctab_sub = (double *)(base + o8); f->yy_sub = (double *)(base + o9);
         f->ictab = (double *)(base + o10); f->yctab = (double *)(base + o11);
         f->yy_part = (double *)(base + o12);
+        f->tile_score = (double *)(base + o13); f->kt_sel = (int32_t *)(base + o14);
+        f->tile_part = (double *)(base + o15);
         f->summary = (double *)(base + o2); f->ulist = (uint16_t *)(base + o3);
         f->ucount = (uint32_t *)(base + o4); f->seed = (int64_t *)(base + o5);
         f->order = (int32_t *)(base + o6); f->sort_ws = base + o7; f->nb = nb; f->Mpad = Mpad;
@@ -1285,9 +1365,18 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         return e ? atoi(e) : PREPASS_KTILES;
     }();
     const int nkt_full = dpad / FKT;
-    const int nkt_used = (prepass_env >= 2 && prepass_env < nkt_full) ? prepass_env : nkt_full;
+    const int nkt_used = (prepass_env >= 2 && prepass_env < nkt_full && nkt_full <= SW_MAX_KT) ? prepass_env : nkt_full;
+    if (nkt_used < nkt_full) {
+        hipLaunchKernelGGL(tile_partial_kernel, dim3((unsigned)nkt_full, TS_RB), dim3(256), 0, s, W_dev,
+                           (int)M, (int)d, dpad, f.tile_part);
+        hipLaunchKernelGGL(tile_score_kernel, dim3((unsigned)nkt_full), dim3(64), 0, s, f.tile_part, (int)M,
+                           dpad, f.tile_score);
+        hipLaunchKernelGGL(tile_select_kernel, dim3(1), dim3(64), 0, s, f.tile_score, nkt_full, nkt_used,
+                           f.kt_sel);
+    }
     hipLaunchKernelGGL(slice_w_tiled_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, W_dev,
-                       (int)M, (int)d, dpad, (int)f.Mpad, seed_stride, Msubpad, nkt_used, f.wt,
+                       (int)M, (int)d, dpad, (int)f.Mpad, seed_stride, Msubpad, nkt_used,
+                       nkt_used < nkt_full ? f.kt_sel : (const int32_t *)nullptr, f.wt,
                        f.wt_sub, f.wscale, f.wl1, f.yy_part);
     hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.wscale, f.wl1, ww_dev, f.yy_part, (int)M,
                        (int)f.Mpad, seed_stride, f.ctab, f.yypad, f.ctab_sub, f.yy_sub,
@@ -1298,7 +1387,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         hipLaunchKernelGGL((sweep_i8_kernel<1, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub,
                            f.yy_sub, f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
-                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad, nkt_used);
+                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad, nkt_used, f.kt_sel);
         g_timer.mark(2, s);
         const int rc = launch_bucket_sort(f.seed, N, M, f.order, f.sort_ws, s);
         if (rc != DBGSOM_OK) return rc;
@@ -1312,12 +1401,12 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         hipLaunchKernelGGL((sweep_i8_kernel<0, 3, 1>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab,
                            f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int64_t *)nullptr, 1, (int)f.Mpad, 0);
+                           (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr);
     else
         hipLaunchKernelGGL((sweep_i8_kernel<0, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab,
                            f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int64_t *)nullptr, 1, (int)f.Mpad, 0);
+                           (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr);
     g_timer.mark(4, s);
     // the three list-length classes write disjoint samples: they run side by side (classes 1 and 2
     // on a second stream forked from the caller's), so that the tail of one launch -- a few long

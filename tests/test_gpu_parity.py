@@ -545,3 +545,28 @@ def test_auto_policy_backs_off_on_near_duplicate_prototypes(o):
     assert kinds[0] == "filtered"                            # probe once ...
     assert kinds[1:] == ["exact"] * 4                        # ... then back off
     assert be.filter_log[0][1] > HipBackend.FILTER_MAX_MEAN_CANDIDATES
+
+
+def test_seed_prepass_finds_the_informative_features(o):
+    """Data whose information sits in two narrow feature ranges (everything else constant): the
+    pre-pass samples the k-tiles in which the prototypes differ most, so the candidate lists stay
+    short; results are exact either way."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(12)
+    N, d, rows, cols = 30_000, 832, 16, 16
+    M = rows * cols
+    X = np.full((N, d), 0.5, dtype=np.float32)
+    centres = rng.normal(size=(40, 128)).astype(np.float32) * 4
+    lab = rng.integers(0, 40, size=N)
+    informative = np.r_[70:134, 450:514]          # k-tiles 1-2 and 7-8 only
+    X[:, informative] = centres[lab] + rng.normal(size=(N, 128)).astype(np.float32)
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    hop = gi.lattice_hops(rows, cols)
+    fi = HipBackend(algorithm="filtered").load(X)
+    ex = HipBackend(algorithm="exact").load(X)
+    rf = fi.epoch(W, hop, 3.0, 1e-3, "compact", True)
+    re_ = ex.epoch(W, hop, 3.0, 1e-3, "compact", True)
+    assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances)
+    counts = fi.filter_counts()
+    assert counts.mean() < 0.5 * M, counts.mean()   # evenly spaced tiles {0, 4, 8} see almost nothing
