@@ -363,7 +363,6 @@ class HipBackend(HotPathBackend):
         if self.algorithm == "auto" and self._filter_backoff > 0:
             return False
         return (self.algorithm != "exact"
-                and (isinstance(self._x_np_dtype, str) or self._x_np_dtype == np.float32)
                 and self.FILTER_MIN_PROTOTYPES <= M <= _native.MAX_PROTOTYPES)
 
     def _hint(self):
@@ -377,11 +376,15 @@ class HipBackend(HotPathBackend):
         N, d = X32.shape
         nbytes = self._lib.dbgsom_filter_planes_bytes(N, d)
         planes = self._torch.empty(nbytes, dtype=self._torch.uint8, device=self.device)
-        _native.call("dbgsom_filter_prepare", self._p(X32), _native.F32, N, d, d, self._p(planes),
+        _native.call("dbgsom_filter_prepare", self._p(X32), self._tcode(X32), N, d, d, self._p(planes),
                      nbytes, self._stream())
         return planes
 
+    def _tcode(self, t):
+        return _native.F32 if t.dtype == self._torch.float32 else _native.F64
+
     def _bmu_filtered_on(self, X32, xxd, planes, Wd, wwd, round_f32, prev_p, order_p, ws_key):
+        # X32: float32 or float64 samples (bfloat16-resident ones come as their float32 copy)
         torch = self._torch
         N, d = X32.shape
         M = Wd.shape[0]
@@ -389,7 +392,7 @@ class HipBackend(HotPathBackend):
         dist = torch.empty((N, 1), dtype=torch.float64, device=self.device)
         need = self._lib.dbgsom_bmu_filtered_workspace_bytes(N, d, M)
         ws = self._buf(ws_key, need)
-        self._timed_call("bmu", "dbgsom_bmu_filtered", self._p(X32), _native.F32, N, d, d,
+        self._timed_call("bmu", "dbgsom_bmu_filtered", self._p(X32), self._tcode(X32), N, d, d,
                          self._p(xxd), self._p(planes), self._p(Wd), M, self._p(wwd),
                          prev_p, order_p, int(self.seed_stride), int(self.sweep_planes), round_f32,
                          self._p(idx),
@@ -411,7 +414,7 @@ class HipBackend(HotPathBackend):
 
     def _query_filter_applies(self, N, d, M, xdtype, k):
         return (k == 1 and self.algorithm != "exact" and not isinstance(xdtype, str)
-                and xdtype == np.float32 and d % 16 == 0 and N >= self.FILTER_MIN_QUERY_ROWS
+                and xdtype in (np.float32, np.float64) and d % 16 == 0 and N >= self.FILTER_MIN_QUERY_ROWS
                 and self.FILTER_MIN_PROTOTYPES <= M <= _native.MAX_PROTOTYPES)
 
     def filter_counts(self):

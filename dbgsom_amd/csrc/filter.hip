@@ -921,15 +921,17 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 // takes the workgroups whose list length falls in its class (<= 16, 17..32, > 32) so that the
 // gathered X tile is streamed once for all but the longest lists (a fourth class of 64 was
 // measured: no gain at C3 / C4, slower at C2).
-template <int JTL>
+template <typename XT, int JTL>
 __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
-    const float *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
+    const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
     const double *__restrict__ W, int M, const double *__restrict__ ww,
     const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
     const uint32_t *__restrict__ ucount, int round_f32, int64_t *__restrict__ idx_out,
     double *__restrict__ dist_out) {
     constexpr int SJ = 16 * JTL;
-    constexpr int S_XT = 128 * KT * 4, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 KB + 2 JTL KB
+    // X tile: 128 rows x KT values, float32 (64-byte rows) or float64 (128-byte rows, laid out like W)
+    constexpr int XROW = KT * (int)sizeof(XT), XCH = XROW / 16, XD = 128 * XROW / 1024 / 4;
+    constexpr int S_XT = 128 * XROW, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 / 16 KB + 2 JTL KB
 #if SUBSET_EXPERIMENT & 64
     __shared__ __attribute__((aligned(16))) char smem[6 * S_STAGE];  // halves the blocks per CU
 #else
@@ -965,16 +967,17 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     best[0].init();
     best[1].init();
 
-    // DMA sources. X tile: 128 rows x 64 B (f32), 8 instructions, wave w issues q = 2w, 2w+1
-    const float *xsrc[2];
+    // DMA sources. X tile: 8 (f32) / 16 (f64) instructions, wave w issues q = XD w .. XD w + XD - 1
+    // = the rows of its own 32 samples
+    const XT *xsrc[XD];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int L = 64 * (2 * wave + u) + lane;
-        const int r = L >> 2, cp = L & 3;
-        const int c = cp ^ ((r >> 1) & 3);
+    for (int u = 0; u < XD; ++u) {
+        const int L = 64 * (XD * wave + u) + lane;
+        const int r = L / XCH, cp = L % XCH;
+        const int c = cp ^ ((r >> 1) & (XCH - 1));
         int64_t p = p0 + r;
         p = p < N ? p : N - 1;
-        xsrc[u] = X + (int64_t)order[p] * ldx + c * 4;
+        xsrc[u] = X + (int64_t)order[p] * ldx + c * (16 / (int)sizeof(XT));
     }
     // W tile: SJ rows x 128 B = 2 JTL instructions (8 rows each), issued by waves 0 .. 2 JTL - 1
     // (JTL = 3: waves 0, 1 take two)
@@ -1010,7 +1013,7 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         if (i_step + i_kt < 3)
 #endif
 #pragma unroll
-        for (int u = 0; u < 2; ++u) fdma16(xsrc[u] + k0, stage + 1024 * (2 * wave + u));
+        for (int u = 0; u < XD; ++u) fdma16(xsrc[u] + k0, stage + 1024 * (XD * wave + u));
 #if SUBSET_EXPERIMENT & 2
         if (i_step + i_kt < 3)
 #endif
@@ -1031,8 +1034,13 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int rb = wave * 32 + u * 16 + lr;
-        b_off[u] = rb * 64 + lq * 4;
-        b_swz[u] = (rb >> 1) & 3;
+        if constexpr (sizeof(XT) == 4) {
+            b_off[u] = rb * XROW + lq * 4;
+            b_swz[u] = (rb >> 1) & 3;
+        } else {
+            b_off[u] = rb * XROW + (lq & 1) * 8;
+            b_swz[u] = (rb >> 1) & 7;
+        }
     }
 
     d4_t acc[JTL][2];
@@ -1056,9 +1064,9 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         STAMP(0);
         // each wavefront waits for ITS OWN DMAs of tile t, the barrier then covers everybody's
         if (t + 1 < ntile) {
-            if (n_wdma == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (n_wdma == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (n_wdma == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XD + 2) : "memory");
+            else if (n_wdma == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XD + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XD) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1087,8 +1095,13 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int cb = ks ^ b_swz[u];
-                b[u] = (double)*reinterpret_cast<const float *>(stage + b_off[u] + cb * 16);
+                if constexpr (sizeof(XT) == 4) {
+                    const int cb = ks ^ b_swz[u];
+                    b[u] = (double)*reinterpret_cast<const float *>(stage + b_off[u] + cb * 16);
+                } else {
+                    const int cb = (2 * ks + (lq >> 1)) ^ b_swz[u];
+                    b[u] = *reinterpret_cast<const double *>(stage + b_off[u] + cb * 16);
+                }
             }
 #endif
 #pragma unroll
@@ -1332,14 +1345,14 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     DBGSOM_REQUIRE(seed_stride >= 0 && seed_stride <= 64, "seed_stride outside [0, 64]");
     DBGSOM_REQUIRE(sweep_planes == 0 || sweep_planes == 2 || sweep_planes == 3, "sweep_planes must be 0, 2 or 3");
     if (sweep_planes == 0) sweep_planes = 2;
-    DBGSOM_REQUIRE(x_dtype == DBGSOM_F32, "the filtered search takes float32 samples");
+    DBGSOM_REQUIRE(x_dtype == DBGSOM_F32 || x_dtype == DBGSOM_F64, "the filtered search takes float32 or float64 samples");
     DBGSOM_REQUIRE(N >= 1 && N < 0x7fffffff && d >= 1 && d % KT == 0 && ldx >= d, "bad sample shape (d must be a multiple of 16)");
     DBGSOM_REQUIRE(M >= 1 && M <= SW_MAX_M, "M outside [1, 16000]");
     DBGSOM_REQUIRE(X_dev && xx_dev && xplanes_dev && W_dev && ww_dev && idx_dev && dist_dev &&
                        workspace_dev, "null pointer");
     DBGSOM_REQUIRE((prev_idx_dev == nullptr) == (order_dev == nullptr),
                    "prev_idx and order come as a pair (both NULL = stateless two-pass search)");
-    DBGSOM_REQUIRE(is_aligned(X_dev, 16) && (ldx * 4) % 16 == 0 && is_aligned(W_dev, 16) &&
+    DBGSOM_REQUIRE(is_aligned(X_dev, 16) && (ldx * (int64_t)dtype_size(x_dtype)) % 16 == 0 && is_aligned(W_dev, 16) &&
                        is_aligned(workspace_dev, 256) && is_aligned(xplanes_dev, 256), "alignment");
     if (workspace_bytes < dbgsom_bmu_filtered_workspace_bytes(N, d, M)) {
         set_error("dbgsom_bmu_filtered: workspace too small");
@@ -1419,9 +1432,16 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         DBGSOM_HIP_CHECK(hipStreamWaitEvent(s2, side.forked, 0));
     }
 #define DBGSOM_SUBSET(JTL, STREAM)                                                                \
-    hipLaunchKernelGGL(subset_exact_kernel<JTL>, dim3((unsigned)f.nb), dim3(NT), 0, STREAM,         \
-                       (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev, \
-                       f.ulist, (int)f.Mpad, f.ucount, round_f32, idx_dev, dist_dev)
+    do {                                                                                          \
+        if (x_dtype == DBGSOM_F32)                                                                \
+            hipLaunchKernelGGL((subset_exact_kernel<float, JTL>), dim3((unsigned)f.nb), dim3(NT), 0, STREAM, \
+                               (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
+                               order_dev, f.ulist, (int)f.Mpad, f.ucount, round_f32, idx_dev, dist_dev); \
+        else                                                                                      \
+            hipLaunchKernelGGL((subset_exact_kernel<double, JTL>), dim3((unsigned)f.nb), dim3(NT), 0, STREAM, \
+                               (const double *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
+                               order_dev, f.ulist, (int)f.Mpad, f.ucount, round_f32, idx_dev, dist_dev); \
+    } while (0)
     DBGSOM_SUBSET(3, s);
     DBGSOM_SUBSET(2, s2);
     DBGSOM_SUBSET(1, s2);

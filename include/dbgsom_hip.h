@@ -114,14 +114,16 @@ int dbgsom_smooth(const double *sums_dev, int64_t M, int64_t d, const float *hop
  * per-sample error eps_i; prototype j stays a candidate of a 128-sample workgroup when
  * r~_ij <= r~_{i,prev(i)} + 2 eps_i for one of its samples (prev = winner of the previous epoch);
  * the exact float64 search (same arithmetic as dbgsom_bmu) then runs on the candidates only.
- * Same reference step as dbgsom_bmu (BaseSom.py:446-464), k = 1, float32 samples, d % 16 == 0.
+ * Same reference step as dbgsom_bmu (BaseSom.py:446-464), k = 1, float32 or float64 samples,
+ * d % 16 == 0 (callers pad rows with zeros: zeros change no fma chain).
  *   xplanes_dev : filled once per fit by dbgsom_filter_prepare (digit planes + row scales of X)
  *   prev_idx_dev: N winners of the previous epoch (any valid indices < M keep the result exact;
  *                 good ones keep the candidate sets small)
  *   order_dev   : the N sample ids bucketed by prev_idx -- the first N int32 of the workspace of
  *                 the previous dbgsom_accumulate call
  *   prev_idx_dev = order_dev = NULL: stateless form -- a coarser int8 pre-pass (three digit
- *                 products, every seed_stride-th prototype; 0 = default 4) finds a starting
+ *                 products, every seed_stride-th prototype; 0 = default 4; on the three 64-feature
+ *                 blocks in which the prototypes differ most) finds a starting
  *                 prototype per sample and the samples are bucketed by it; nothing from an earlier
  *                 call is used.  The seed only sets the candidate threshold: ANY seed gives the
  *                 exact result, a nearer one shorter candidate lists.

@@ -570,3 +570,28 @@ def test_seed_prepass_finds_the_informative_features(o):
     assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances)
     counts = fi.filter_counts()
     assert counts.mean() < 0.5 * M, counts.mean()   # evenly spaced tiles {0, 4, 8} see almost nothing
+
+
+@pytest.mark.parametrize("N,d,rows,cols", [(9000, 96, 14, 14), (5000, 200, 20, 21)])
+def test_float64_samples_take_the_filtered_search(o, N, d, rows, cols):
+    """float64 samples: digit planes from the float64 rows, exact re-evaluation on float64 tiles."""
+    from dbgsom_amd.backend import HipBackend
+
+    M = rows * cols
+    X32, _ = gi.blobs_f32(N, d, 555)
+    X = X32.astype(np.float64) + np.random.default_rng(6).normal(scale=1e-9, size=(N, d))  # not float32-representable
+    W = X[np.random.default_rng(7).choice(N, M, replace=False)] + 1e-3
+    hop = gi.lattice_hops(rows, cols)
+    fi = HipBackend(algorithm="filtered").load(X)
+    ex = HipBackend(algorithm="exact").load(X)
+    for e in range(2):
+        rf = fi.epoch(W, hop, 2.0, 1e-3, "compact", True)
+        re_ = ex.epoch(W, hop, 2.0, 1e-3, "compact", True)
+        assert fi._planes is not None
+        assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances)
+        assert np.array_equal(rf.new_weights, re_.new_weights)
+        W = re_.new_weights
+    pick = np.random.default_rng(0).choice(N, 1200, replace=False)
+    rd, ri = o.bmu_chain(X[pick], W, 1)
+    d1, i1 = fi.bmu(W, 1)
+    assert np.array_equal(i1[pick], ri) and np.array_equal(d1[pick], rd)
