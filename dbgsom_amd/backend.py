@@ -192,9 +192,8 @@ class HipBackend(HotPathBackend):
     # exact all-pairs kernel is cheaper: use it for the next FILTER_BACKOFF epochs, then re-probe
     FILTER_MAX_MEAN_CANDIDATES = 320
     FILTER_BACKOFF = 8
-    # the stateless seed pre-pass looks at every seed_stride-th prototype (results do not depend
-    # on it; 4 balances the pre-pass against longer candidate lists at the bench shapes)
-    seed_stride = 4
+    # the stateless seed pre-pass looks at every seed_stride-th prototype (results do not depend on it)
+    seed_stride = 0   # 0 = the library's choice (one 256-prototype chunk, at least every 4th)
     # digit planes of the candidate sweep: 2 = three int8 digit products, 3 = six (tighter bound,
     # twice the MFMA work); results do not depend on it
     sweep_planes = int(os.environ.get("DBGSOM_SWEEP_PLANES", "2"))

@@ -122,7 +122,7 @@ int dbgsom_smooth(const double *sums_dev, int64_t M, int64_t d, const float *hop
  *   order_dev   : the N sample ids bucketed by prev_idx -- the first N int32 of the workspace of
  *                 the previous dbgsom_accumulate call
  *   prev_idx_dev = order_dev = NULL: stateless form -- a coarser int8 pre-pass (three digit
- *                 products, every seed_stride-th prototype; 0 = default 4; on the three 64-feature
+ *                 products, every seed_stride-th prototype; 0 = default: ceil(M / 256), at least 4; on the three 64-feature
  *                 blocks in which the prototypes differ most) finds a starting
  *                 prototype per sample and the samples are bucketed by it; nothing from an earlier
  *                 call is used.  The seed only sets the candidate threshold: ANY seed gives the
