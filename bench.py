@@ -264,7 +264,19 @@ def main():
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL prints a version banner on stdout when the first communicator comes up: create it
+        # here with stdout pointed at stderr, so that the ONE line on stdout is the JSON result
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            td.all_reduce(torch.zeros(1, device=device))
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     h = Harness(torch, td, args, local, world, grouped)
 
     n_gpu, d, rows, cols, seed, cfg_name = WORKLOADS[args.workload]
