@@ -595,3 +595,46 @@ def test_float64_samples_take_the_filtered_search(o, N, d, rows, cols):
     rd, ri = o.bmu_chain(X[pick], W, 1)
     d1, i1 = fi.bmu(W, 1)
     assert np.array_equal(i1[pick], ri) and np.array_equal(d1[pick], rd)
+
+
+def test_filtered_search_randomised_shapes_dtypes_and_options():
+    """25 random configurations (float32 / float64 / bfloat16 samples, any feature count, 129-2600
+    prototypes, clustered / uniform / integer / badly scaled data, seed strides, both sweep
+    variants, stateless and hinted): winners, distances and new prototypes of the filtered search
+    are those of the all-pairs kernel, bit for bit (`tools/stress_filtered.py` is the long form)."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(20260101)
+    for case in range(25):
+        N = int(rng.integers(130, 12000))
+        d = int(rng.choice([16, 17, 31, 48, 64, 100, 129, 256, 500, 784]))
+        M = int(rng.integers(129, 2600))
+        kind = rng.choice(["blobs", "uniform", "dups", "scaled"])
+        dt = rng.choice(["f32", "f64", "bf16"])
+        if kind == "blobs":
+            c = rng.normal(size=(int(rng.integers(2, 50)), d)) * 4
+            X = c[rng.integers(0, len(c), size=N)] + rng.normal(size=(N, d))
+        elif kind == "uniform":
+            X = rng.uniform(-1, 1, size=(N, d))
+        elif kind == "dups":
+            X = rng.integers(-2, 3, size=(N, d)).astype(np.float64)
+        else:
+            X = rng.normal(size=(N, d)) * np.exp(rng.uniform(-6, 6, size=(1, d)))
+        X = X.astype(np.float64 if dt == "f64" else np.float32)
+        W = X[rng.choice(N, M, replace=M > N)].astype(np.float64)
+        storage = "bf16" if dt == "bf16" else None
+        ex = HipBackend(algorithm="exact").load(X, storage=storage)
+        fi = HipBackend(algorithm="filtered_hint" if rng.random() < 0.5 else "filtered").load(X, storage=storage)
+        fi.seed_stride = int(rng.choice([0, 1, 2, 8, 32]))
+        fi.sweep_planes = int(rng.choice([2, 3]))
+        hop = np.abs(np.subtract.outer(np.arange(M), np.arange(M))).astype(np.float64)
+        for e in range(2):
+            re_ = ex.epoch(W, hop, 1.5, 1e-3, "aligned", True)
+            rf = fi.epoch(W, hop, 1.5, 1e-3, "aligned", True)
+            tag = f"case {case} epoch {e}: N={N} d={d} M={M} {kind} {dt}"
+            assert np.array_equal(re_.winners, rf.winners), tag
+            assert np.array_equal(re_.distances, rf.distances), tag
+            assert np.array_equal(re_.new_weights, rf.new_weights, equal_nan=True), tag
+            W = np.nan_to_num(re_.new_weights)
+        ex.release()
+        fi.release()
