@@ -48,9 +48,9 @@ I8_MFMA_PEAK_TOPS = 5033.0   # 256 x 4 x 2.4 GHz x 65536 op / 32 cycles (v_mfma_
 # HBM-side bytes of one full-sweep launch at C4 from the PMC passes committed under profiles/
 # (FETCH_SIZE x 2 per the gfx950 correction); not measurable inside this process.  Keyed by the
 # number of digit planes the sweep reads (2 -> sweep_i8_kernel<0,2,2>, 3 -> sweep_i8_kernel<0,3,1>)
-SWEEP_TRAFFIC_C4_BYTES = {2: 7.90e9, 3: 2.42e10}
-SWEEP_KERNEL = {2: "sweep_i8_kernel<0,2,2>", 3: "sweep_i8_kernel<0,3,1>"}
-SWEEP_PRODUCTS = {2: 3, 3: 6}   # int8 digit products kept per (sample, prototype, k)
+SWEEP_TRAFFIC_C4_BYTES = {1: None, 2: 7.90e9, 3: 2.42e10}
+SWEEP_KERNEL = {1: "sweep_i8_kernel<0,1,4>", 2: "sweep_i8_kernel<0,2,2>", 3: "sweep_i8_kernel<0,3,1>"}
+SWEEP_PRODUCTS = {1: 1, 2: 3, 3: 6}   # int8 digit products kept per (sample, prototype, k)
 
 
 def lattice_hops(rows, cols):
@@ -176,6 +176,7 @@ def frozen_map_regime(h, algorithm, X, W0, hop, sigma, gamma):
         stage = dict(zip(("slice_w", "prepass", "bucket_sort", "sweep", "exact_on_candidates"),
                          [float(v) for v in ms]))
         _native.call("dbgsom_filter_timing", 0)
+        stage["sweep_planes"] = int(be._planes_used)   # what the adaptive policy settled on
         counts = be.filter_counts()
         stage["candidates_per_workgroup"] = {"mean": float(counts.mean()),
                                              "p90": float(np.percentile(counts, 90)),
@@ -320,8 +321,7 @@ def main():
             roof = exact_roof
         else:
             dpad = (d + 63) // 64 * 64
-            from dbgsom_amd.backend import HipBackend as _HB
-            planes = int(_HB.sweep_planes)
+            planes = int(stage.get("sweep_planes", 2))
             ops = 2.0 * n_gpu * M * dpad * SWEEP_PRODUCTS[planes]  # int8 ops the sweep executes
             ach = ops / (stage["sweep"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": SWEEP_KERNEL[planes], "dtype": "i8",

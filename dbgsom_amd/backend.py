@@ -194,9 +194,9 @@ class HipBackend(HotPathBackend):
     FILTER_BACKOFF = 8
     # the stateless seed pre-pass looks at every seed_stride-th prototype (results do not depend on it)
     seed_stride = 0   # 0 = the library's choice (one 256-prototype chunk, at least every 4th)
-    # digit planes of the candidate sweep: 2 = three int8 digit products, 3 = six (tighter bound,
-    # twice the MFMA work); results do not depend on it
-    sweep_planes = int(os.environ.get("DBGSOM_SWEEP_PLANES", "2"))
+    # digit planes of the candidate sweep: 1 = one int8 digit product (coarsest bound, half the
+    # sweep time of 2), 2 = three, 3 = six (tightest, twice the time of 2); results do not depend on it
+    sweep_planes = int(os.environ.get("DBGSOM_SWEEP_PLANES", "0"))   # 0 = adaptive (see _adapt_planes)
 
     def __init__(self, device: Optional[int] = None, algorithm: str = "auto"):
         """algorithm (all give IDENTICAL results):
@@ -238,7 +238,10 @@ class HipBackend(HotPathBackend):
         self._order = None       # sample ids bucketed by those winners (device, int32)
         self._filter_backoff = 0
         self._filtered_this_epoch = False
-        self.filter_log = []     # (epoch kind, mean candidates) of the last epochs, diagnostics
+        self.filter_log = []     # (epoch kind, mean candidates, digit planes) of the last epochs
+        self._plane_state = {}
+        self._planes_next = 1
+        self._planes_used = 1
         # bench hook: a list here collects (name, start, end) HIP events recorded on the stream
         # the kernels are launched on
         self.kernel_events = None
@@ -391,9 +394,10 @@ class HipBackend(HotPathBackend):
         dist = torch.empty((N, 1), dtype=torch.float64, device=self.device)
         need = self._lib.dbgsom_bmu_filtered_workspace_bytes(N, d, M)
         ws = self._buf(ws_key, need)
+        self._planes_used = self._planes_for_call()
         self._timed_call("bmu", "dbgsom_bmu_filtered", self._p(X32), self._tcode(X32), N, d, d,
                          self._p(xxd), self._p(planes), self._p(Wd), M, self._p(wwd),
-                         prev_p, order_p, int(self.seed_stride), int(self.sweep_planes), round_f32,
+                         prev_p, order_p, int(self.seed_stride), int(self._planes_used), round_f32,
                          self._p(idx),
                          self._p(dist), self._p(ws), ws.numel(), self._stream())
         return dist, idx
@@ -596,14 +600,57 @@ class HipBackend(HotPathBackend):
                 self.filter_log.append(("exact", None))
             return
         mean = float(self.filter_counts().mean())
-        self.filter_log.append(("filtered", mean))
+        self.filter_log.append(("filtered", mean, self._planes_used))
         del self.filter_log[:-64]
+        if int(self.sweep_planes) == 0:
+            self._adapt_planes(mean, self._last_filter_M)
         if self.algorithm == "auto":
             if mean > self.FILTER_MAX_MEAN_CANDIDATES:  # exponential back-off, capped
                 self._filter_fail = min(getattr(self, "_filter_fail", 0) + 1, 6)
                 self._filter_backoff = self.FILTER_BACKOFF << (self._filter_fail - 1)
             else:
                 self._filter_fail = 0
+
+    # Digit planes of the candidate sweep when sweep_planes == 0: one product costs about half of
+    # three, six about twice as much; a list entry of the exact stage costs about as much as
+    # sweeping 16 prototypes with three products (both scale with N and d).  Start with one
+    # product; look at a finer sweep when even emptying the lists would pay for it, keep whichever
+    # is cheaper in this model, look again every PLANES_REPROBE epochs.  Results never depend on it.
+    SWEEP_COST = {1: 0.54, 2: 1.0, 3: 1.96}
+    LIST_COST = 16.4
+    PLANES_REPROBE = 64
+
+    def _plane_cost(self, p, mean, M):
+        return self.SWEEP_COST[p] * M + self.LIST_COST * mean
+
+    def _adapt_planes(self, mean, M):
+        st = self._plane_state
+        p = self._planes_used
+        if st.get("M") != M:            # another map size: what was learnt no longer applies
+            st.clear()
+            st.update(M=M, known={}, hold=0)
+        st["known"][p] = mean
+        if st["hold"] > 0:
+            st["hold"] -= 1
+            if st["hold"] == 0:
+                st["known"] = {p: mean}  # forget the alternatives, they get another look
+            return
+        known = st["known"]
+        best = min(known, key=lambda q: self._plane_cost(q, known[q], M))
+        # a finer sweep can at best empty the lists; a coarser one at worst ... is simply tried
+        finer, coarser = best + 1, best - 1
+        if finer <= 3 and finer not in known and \
+                self.LIST_COST * known[best] > (self.SWEEP_COST[finer] - self.SWEEP_COST[best]) * M:
+            self._planes_next = finer
+        elif coarser >= 1 and coarser not in known:
+            self._planes_next = coarser
+        else:
+            self._planes_next = best
+            st["hold"] = self.PLANES_REPROBE
+
+    def _planes_for_call(self):
+        fixed = int(self.sweep_planes)
+        return fixed if fixed else self._planes_next
 
     # -- f-2 / f-3: reductions that keep the N-sized arrays in HBM -----------------------------
     def _bmu_resident_dev(self, W, k):

@@ -285,10 +285,29 @@ __global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict_
 // sweep applies.
 // With two digit planes (products a + b <= 1) the dropped set also holds the three level-2
 // products: d * 128 * 128 * (3 * 65536 + 2 * 256 + 1) * s t / F^2.
+// T = sum over the kept digit products of P_level 2^(16 - 8 level), from the per-level int32
+// accumulators (exact: |T| < 2^53); sweep_T_scaled = T / sweep_tscale(planes): what the marking
+// test uses (the scale is folded into the reciprocal tables)
+template <int PLANES>
+__device__ __forceinline__ double sweep_T_scaled(int a0, int a1, int a2) {
+    if constexpr (PLANES == 1) return (double)a0;
+    else if constexpr (PLANES == 2) return (double)a0 * 256.0 + (double)a1;
+    else return ((double)a0 * 256.0 + (double)a1) * 256.0 + (double)a2;
+}
+template <int PLANES>
+__device__ __forceinline__ double sweep_T(int a0, int a1, int a2) {
+    constexpr double scale = PLANES == 1 ? 65536.0 : (PLANES == 2 ? 256.0 : 1.0);
+    return sweep_T_scaled<PLANES>(a0, a1, a2) * scale;
+}
+static double sweep_tscale(int planes) { return planes == 1 ? 65536.0 : (planes == 2 ? 256.0 : 1.0); }
+
 __device__ __forceinline__ double filter_eps(double s, double l1x, double xx, double l1w_max,
                                              double t_max, double yy_max, int d, int planes) {
     const double quant = (s * l1w_max + t_max * l1x) / (2.0 * FQ) + (double)d * s * t_max / (4.0 * FQ * FQ);
-    const double per_k = 16384.0 * (planes >= 3 ? 513.0 : (3.0 * 65536.0 + 513.0));
+    // dropped digit products per feature, in units of 128 * 128: levels 3, 4 / 2 .. 4 / 1 .. 4
+    const double per_k = 16384.0 * (planes >= 3 ? 513.0
+                                    : planes == 2 ? (3.0 * 65536.0 + 513.0)
+                                                  : (2.0 * 16777216.0 + 3.0 * 65536.0 + 513.0));
     const double dropped = (double)d * per_k * s * t_max / (FQ * FQ);
     const double rounding = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xx + yy_max);
     return 2.0 * (quant + dropped) * (1.0 + 1e-7) + rounding;
@@ -439,12 +458,15 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         a0 = __builtin_amdgcn_sdot4(xv[0][e], wv[0][e], a0, false);
-                        a1 = __builtin_amdgcn_sdot4(xv[0][e], wv[1][e], a1, false);
-                        a1 = __builtin_amdgcn_sdot4(xv[1][e], wv[0][e], a1, false);
+                        if constexpr (PLANES >= 2) {
+                            a1 = __builtin_amdgcn_sdot4(xv[0][e], wv[PLANES >= 2 ? 1 : 0][e], a1, false);
+                            a1 = __builtin_amdgcn_sdot4(xv[PLANES >= 2 ? 1 : 0][e], wv[0][e], a1, false);
+                        }
                         if constexpr (PLANES == 3) {
-                            a2 = __builtin_amdgcn_sdot4(xv[0][e], wv[2][e], a2, false);
-                            a2 = __builtin_amdgcn_sdot4(xv[1][e], wv[1][e], a2, false);
-                            a2 = __builtin_amdgcn_sdot4(xv[2][e], wv[0][e], a2, false);
+                            constexpr int P1 = PLANES >= 2 ? 1 : 0, P2 = PLANES >= 3 ? 2 : 0;
+                            a2 = __builtin_amdgcn_sdot4(xv[0][e], wv[P2][e], a2, false);
+                            a2 = __builtin_amdgcn_sdot4(xv[P1][e], wv[P1][e], a2, false);
+                            a2 = __builtin_amdgcn_sdot4(xv[P2][e], wv[0][e], a2, false);
                         }
                     }
                 }
@@ -456,9 +478,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                 a2 += __shfl_xor(a2, m, 64);
             }
             if (need && q == 0) {
-                double T = (double)a0 * 256.0 + (double)a1;
-                if constexpr (PLANES == 3) T = T * 256.0 + (double)a2;
-                else T = T * 256.0;
+                const double T = sweep_T<PLANES>(a0, a1, a2);
                 const double sv = sx[i], xv2 = xx[i];
                 const double e2 = 2.0 * filter_eps(sv, l1x[i], xv2, summary[0], summary[1], summary[2], d, PLANES);
                 thr_s[il] = (sv * (craw[pj] * T) - yraw[pj]) - e2;  // = |x|^2 - (r~_seed + 2 eps)
@@ -596,9 +616,11 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #pragma unroll
         for (int lv = 0; lv < NLV; ++lv)
 #pragma unroll
-            for (int px = 0; px <= lv; ++px) {
+            for (int px = 0; px <= lv; ++px)
 #pragma unroll
-                for (int jt = 0; jt < JT; ++jt)
+            for (int jh = 0; jh < JT; jh += 2) {  // groups of (at most) two prototype tiles x two sample tiles
+#pragma unroll
+                for (int jt = jh; jt < jh + 2 && jt < JT; ++jt)
 #pragma unroll
                     for (int it = 0; it < 2; ++it)
 #if SWEEP_EXPERIMENT & 4
@@ -642,7 +664,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     load_frags(0, 0, f0);
     // (measured, no effect beyond run-to-run noise: s_setprio for the later-slot wavefronts, slots
     // mixed across the SIMDs instead of by wavefront half)
-    const int dma_slot = wave >= 4 ? 1 : 0;  // product group behind which this wave issues DMAs
+    constexpr int N_GROUPS = NLV * (NLV + 1) / 2 * ((JT + 1) / 2);  // product groups per k-step
+    const int dma_slot = (wave >= 4 && N_GROUPS > 1) ? 1 : 0;  // group behind which this wave issues DMAs
 #if SWEEP_EXPERIMENT & 256
     __shared__ unsigned wstamps[2 * 10 * 5];
     const uint64_t w_start = __builtin_amdgcn_s_memtime();
@@ -732,12 +755,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             // the tile loop those 64 bit masks / table addresses cost the fragment registers
             int jl0 = wj * 32 * JT + 4 * lh;
             asm volatile("" : "+v"(jl0));
-            auto combine = [&](int a0, int a1, int a2) -> double {  // exact: |.| < 2^53
-                double T = (double)a0 * 256.0 + (double)a1;
-                if constexpr (PLANES == 3) T = T * 256.0 + (double)a2;
-                else T = T * 256.0;
-                return T;
-            };
+            auto combine = [&](int a0, int a1, int a2) -> double { return sweep_T<PLANES>(a0, a1, a2); };
+            constexpr int L1 = NLV >= 2 ? 1 : 0, L2 = NLV >= 3 ? 2 : 0;  // level indices that exist
             if constexpr (MODE == 0) {
                 if (has_prev) {  // bound from the seed: thr_i = r~(i, seed_i) + 2 eps_i
                     // the seed's own products are picked by selects, not 64 divergent branches
@@ -752,8 +771,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                                 const int jl = jl0 + jt * 32 + (r & 3) + 8 * (r >> 2);
                                 const bool sel = jl == want;
                                 a0s = sel ? acc[jt][it][0][r] : a0s;
-                                a1s = sel ? acc[jt][it][1][r] : a1s;
-                                if constexpr (PLANES == 3) a2s = sel ? acc[jt][it][2][r] : a2s;
+                                if constexpr (PLANES >= 2) a1s = sel ? acc[jt][it][L1][r] : a1s;
+                                if constexpr (PLANES == 3) a2s = sel ? acc[jt][it][L2][r] : a2s;
                                 jls = sel ? jl : jls;
                             }
                         if (jls >= 0)
@@ -795,12 +814,11 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #pragma unroll
                         for (int it = 0; it < 2; ++it) {
                             if constexpr (MODE == 0) {
-                                double Tp = (double)acc[jt][it][0][r] * 256.0 + (double)acc[jt][it][1][r];
-                                if constexpr (PLANES == 3) Tp = Tp * 256.0 + (double)acc[jt][it][2][r];
+                                const double Tp = sweep_T_scaled<PLANES>(acc[jt][it][0][r], acc[jt][it][L1][r],
+                                                                         acc[jt][it][L2][r]);
                                 pass |= __builtin_amdgcn_ballot_w64((A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp);
                             } else {
-                                const double T = combine(acc[jt][it][0][r], acc[jt][it][1][r],
-                                                         PLANES == 3 ? acc[jt][it][NLV - 1][r] : 0);
+                                const double T = combine(acc[jt][it][0][r], acc[jt][it][L1][r], acc[jt][it][L2][r]);
                                 const double rv = y4[i] - s_i[it] * (c4[i] * T);  // r~ - |x_i|^2
                                 if (j < M && rv < bestv[it]) { bestv[it] = rv; bestj[it] = j * jstride; }
                             }
@@ -1210,7 +1228,7 @@ struct FilterWs {
     int64_t nb, Mpad;
 };
 static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_t M) {
-    const int64_t Mpad = (M + 255) / 256 * 256, nb = (N + 127) / 128, dpad = filter_dpad(d);
+    const int64_t Mpad = (M + 511) / 512 * 512, nb = (N + 127) / 128, dpad = filter_dpad(d);  // whole 512-prototype chunks
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t ow = take((size_t)3 * Mpad * dpad), ows = take((size_t)3 * Mpad * dpad);
@@ -1343,7 +1361,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                         int round_f32, int64_t *idx_dev, double *dist_dev, void *workspace_dev,
                         size_t workspace_bytes, void *stream) {
     DBGSOM_REQUIRE(seed_stride >= 0 && seed_stride <= 64, "seed_stride outside [0, 64]");
-    DBGSOM_REQUIRE(sweep_planes == 0 || sweep_planes == 2 || sweep_planes == 3, "sweep_planes must be 0, 2 or 3");
+    DBGSOM_REQUIRE(sweep_planes >= 0 && sweep_planes <= 3, "sweep_planes must be 0 .. 3");
     if (sweep_planes == 0) sweep_planes = 2;
     DBGSOM_REQUIRE(x_dtype == DBGSOM_F32 || x_dtype == DBGSOM_F64, "the filtered search takes float32 or float64 samples");
     DBGSOM_REQUIRE(N >= 1 && N < 0x7fffffff && d >= 1 && d % KT == 0 && ldx >= d, "bad sample shape (d must be a multiple of 16)");
@@ -1398,7 +1416,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                        f.wt_sub, f.wscale, f.wl1, f.yy_part);
     hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.wscale, f.wl1, ww_dev, f.yy_part, (int)M,
                        (int)f.Mpad, seed_stride, f.ctab, f.yypad, f.ctab_sub, f.yy_sub,
-                       sweep_planes == 2 ? 256.0 : 1.0, f.ictab, f.yctab, f.summary);
+                       sweep_tscale(sweep_planes), f.ictab, f.yctab, f.summary);
     g_timer.mark(1, s);
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
@@ -1415,7 +1433,14 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         g_timer.mark(2, s);
     }
     g_timer.mark(3, s);
-    if (sweep_planes == 3)
+#define DBGSOM_SWEEP(P, J)                                                                         \
+    hipLaunchKernelGGL((sweep_i8_kernel<0, P, J>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,   \
+                       xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab, f.yypad,    \
+                       f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad,     \
+                       f.ucount, (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr)
+    if (sweep_planes == 1) {  // one digit product: 128 x 512 tile (128 x 256 for small maps)
+        if (M > 256) DBGSOM_SWEEP(1, 4); else DBGSOM_SWEEP(1, 2);
+    } else if (sweep_planes == 3)
         hipLaunchKernelGGL((sweep_i8_kernel<0, 3, 1>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab,
                            f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
@@ -1451,6 +1476,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     DBGSOM_SUBSET(2, s2);
     DBGSOM_SUBSET(1, s2);
 #undef DBGSOM_SUBSET
+#undef DBGSOM_SWEEP
     if (fork) {
         DBGSOM_HIP_CHECK(hipEventRecord(side.joined, s2));
         DBGSOM_HIP_CHECK(hipStreamWaitEvent(s, side.joined, 0));

@@ -564,6 +564,7 @@ def test_seed_prepass_finds_the_informative_features(o):
     W = X[rng.choice(N, M, replace=False)].astype(np.float64)
     hop = gi.lattice_hops(rows, cols)
     fi = HipBackend(algorithm="filtered").load(X)
+    fi.sweep_planes = 2     # (a constant 0.5 in 700 features: too coarse for the one-product sweep)
     ex = HipBackend(algorithm="exact").load(X)
     rf = fi.epoch(W, hop, 3.0, 1e-3, "compact", True)
     re_ = ex.epoch(W, hop, 3.0, 1e-3, "compact", True)
@@ -626,7 +627,7 @@ def test_filtered_search_randomised_shapes_dtypes_and_options():
         ex = HipBackend(algorithm="exact").load(X, storage=storage)
         fi = HipBackend(algorithm="filtered_hint" if rng.random() < 0.5 else "filtered").load(X, storage=storage)
         fi.seed_stride = int(rng.choice([0, 1, 2, 8, 32]))
-        fi.sweep_planes = int(rng.choice([2, 3]))
+        fi.sweep_planes = int(rng.choice([0, 1, 2, 3]))   # 0 = adaptive
         hop = np.abs(np.subtract.outer(np.arange(M), np.arange(M))).astype(np.float64)
         for e in range(2):
             re_ = ex.epoch(W, hop, 1.5, 1e-3, "aligned", True)
@@ -638,3 +639,32 @@ def test_filtered_search_randomised_shapes_dtypes_and_options():
             W = np.nan_to_num(re_.new_weights)
         ex.release()
         fi.release()
+
+
+def test_adaptive_digit_planes_settle_on_the_cheaper_sweep(o):
+    """sweep_planes = 0: starts with the one-product sweep; keeps it where the lists stay short
+    (clustered data), moves to three products where the coarse bound marks the whole map."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(3)
+    N, d, rows, cols = 12_000, 256, 16, 20
+    M = rows * cols
+    hop = gi.lattice_hops(rows, cols)
+    Xb, _ = gi.blobs_f32(N, d, 77)
+    Xu = (rng.uniform(0.45, 0.55, size=(N, d))).astype(np.float32)   # tiny spread around a big mean
+    for X, settle in ((Xb, 0), (Xu, None)):
+        W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+        be = HipBackend(algorithm="filtered").load(X)
+        ex = HipBackend(algorithm="exact").load(X)
+        assert int(be.sweep_planes) == 0
+        for e in range(5):
+            r = be.epoch(W, hop, 2.0, 1e-3, "compact", True)
+            q = ex.epoch(W, hop, 2.0, 1e-3, "compact", True)
+            assert np.array_equal(r.winners, q.winners) and np.array_equal(r.distances, q.distances)
+        used = [entry[2] for entry in be.filter_log]
+        means = {p: m for (_, m, p) in be.filter_log}
+        assert used[0] == 1 and used[-1] == used[-2] and be._plane_state["hold"] > 0, used   # settled
+        best = min(means, key=lambda p: be._plane_cost(p, means[p], M))
+        assert used[-1] == best, (used, means)
+        if settle is None:
+            assert used[-1] >= 2, (used, means)
