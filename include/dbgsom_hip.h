@@ -129,7 +129,9 @@ int dbgsom_smooth(const double *sums_dev, int64_t M, int64_t d, const float *hop
  *                 exact result, a nearer one shorter candidate lists.
  *   sweep_planes: digit planes per operand in the candidate sweep: 3 = six digit products (error
  *                 bound ~1e-6 of |x||w|), 2 = three products (bound ~3e-4, half the MFMA work and
- *                 two thirds of the traffic, somewhat longer candidate lists); 0 = default (2). */
+ *                 two thirds of the traffic, somewhat longer candidate lists), 1 = one product
+ *                 (bound ~5e-2, half the time of 2 again; enough where the candidates are the
+ *                 sample's cluster anyway); 0 = default (2).  Results never depend on it. */
 size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d);
 int dbgsom_filter_prepare(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                           void *planes_dev, size_t planes_bytes, void *stream);
