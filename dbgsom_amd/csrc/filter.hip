@@ -1420,7 +1420,16 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     g_timer.mark(1, s);
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
-        hipLaunchKernelGGL((sweep_i8_kernel<1, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
+        // the pre-pass is as coarse as the sweep it seeds: one product for the one-product sweep
+        // (seeds need not be good, only cheap), three otherwise (data on which the coarse bound
+        // fails also gets useless seeds from a one-product pre-pass)
+        if (sweep_planes == 1)
+            hipLaunchKernelGGL((sweep_i8_kernel<1, 1, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
+                           xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub,
+                           f.yy_sub, f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
+                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad, nkt_used, f.kt_sel);
+        else
+            hipLaunchKernelGGL((sweep_i8_kernel<1, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub,
                            f.yy_sub, f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
                            f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad, nkt_used, f.kt_sel);
