@@ -58,10 +58,14 @@ def lattice_hops(rows, cols):
     return (np.abs(ii[:, None] - ii[None]) + np.abs(jj[:, None] - jj[None])).astype(np.float64)
 
 
-def make_shard(torch, n, d, seed, device):
-    """Gaussian blobs: 32 centres ~ N(0, 16 I), unit noise; generated in HBM."""
+def make_shard(torch, n, d, seed, device, rank=0):
+    """This rank's rows of the Gaussian-blob data set of SURVEY.md 8(d): 32 centres ~ N(0, 16 I)
+    (ONE set for the whole data set, from `seed`), unit noise; the rows come from the stream
+    `seed + rank`.  Generated in HBM."""
     gen = torch.Generator(device=device).manual_seed(seed)
     centers = torch.randn(32, d, device=device, generator=gen) * 4.0
+    if rank:  # rank 0 goes on with the stream that drew the centres
+        gen = torch.Generator(device=device).manual_seed(seed + rank)
     X = torch.empty((n, d), dtype=torch.float32, device=device)
     step = 100_000
     for s in range(0, n, step):  # chunked: no N x d float64 temporaries
@@ -284,7 +288,7 @@ def main():
     if args.samples_per_gpu:
         n_gpu = args.samples_per_gpu
     M = rows * cols
-    X = make_shard(torch, n_gpu, d, seed + rank, device)
+    X = make_shard(torch, n_gpu, d, seed, device, rank=rank)
     if args.workload in BF16_WORKLOADS:
         X = X.to(torch.bfloat16)  # storage dtype of the workload; HipBackend.load_device keeps it
 
