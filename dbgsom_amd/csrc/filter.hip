@@ -503,6 +503,10 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         }
     }
     double bestv[2] = {INFINITY, INFINITY};  // MODE 1: running arg-min of r~
+#if SWEEP_EXPERIMENT & 512
+    unsigned npass = 0;  // (sample, prototype) pairs that pass the marking test
+    if (tid == 0) misc[3] = 0;
+#endif
     int bestj[2] = {0, 0};
 
     // ---- DMA sources: per plane, wave w loads X rows 16w..16w+15 and W rows 16w + 128u ..+15 ----
@@ -816,7 +820,13 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                             if constexpr (MODE == 0) {
                                 const double Tp = sweep_T_scaled<PLANES>(acc[jt][it][0][r], acc[jt][it][L1][r],
                                                                          acc[jt][it][L2][r]);
+#if SWEEP_EXPERIMENT & 512
+                                const uint64_t b1 = __builtin_amdgcn_ballot_w64((A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp);
+                                npass += __popcll(b1);
+                                pass |= b1;
+#else
                                 pass |= __builtin_amdgcn_ballot_w64((A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp);
+#endif
                             } else {
                                 const double T = combine(acc[jt][it][0][r], acc[jt][it][L1][r], acc[jt][it][L2][r]);
                                 const double rv = y4[i] - s_i[it] * (c4[i] * T);  // r~ - |x_i|^2
@@ -895,6 +905,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     }
 
     // ---- compact the marked prototypes, ascending ------------------------------------------------
+#if SWEEP_EXPERIMENT & 512
+    if (lane == 0) atomicAdd(&misc[3], (int)npass);
+#endif
     __syncthreads();
     if (wave == 0) {
         uint32_t base = 0;
@@ -917,6 +930,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             base += __shfl(pre, 63, 64);
         }
         if (lane == 0) ucount[blockIdx.x] = base;
+#if SWEEP_EXPERIMENT & 512
+        if (lane == 0) reinterpret_cast<unsigned *>(out + 512)[0] = (unsigned)misc[3];
+#endif
 #if SWEEP_EXPERIMENT & 256
         {   // stamps of waves 0 and 4 behind the list: uint32 at uint16 offset 512 of this row
             unsigned *dbg = reinterpret_cast<unsigned *>(out + 512);
@@ -1495,7 +1511,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     return launch_status("filtered bmu kernels");
 }
 
-#if SWEEP_EXPERIMENT & 256
+#if SWEEP_EXPERIMENT & (256 | 512)
 size_t dbgsom_debug_ulist_offset(int64_t N, int64_t d, int64_t M) {
     FilterWs f;
     carve_filter(&f, (char *)nullptr, N, d, M);
