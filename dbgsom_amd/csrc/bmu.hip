@@ -265,11 +265,19 @@ __global__ __launch_bounds__(NORM_THREADS) void row_sqnorms_kernel(const T *__re
             tile[r][c] = (row < rows && k < d) ? widen(A[row * ld + k]) : 0.0;
         }
         __syncthreads();
-        if (tid < NR) {
+        if (tid < NR) {  // one sequential fma chain per row (the order is the specification)
             const int kmax = min(NK, d - k0);
-            for (int kk = 0; kk < kmax; ++kk) {
-                const double v = tile[tid][kk];
-                acc = fma(v, v, acc);
+            if (kmax == NK) {  // whole tile: LDS reads batched 16 ahead of the dependent chain
+#pragma unroll 16
+                for (int kk = 0; kk < NK; ++kk) {
+                    const double v = tile[tid][kk];
+                    acc = fma(v, v, acc);
+                }
+            } else {
+                for (int kk = 0; kk < kmax; ++kk) {
+                    const double v = tile[tid][kk];
+                    acc = fma(v, v, acc);
+                }
             }
         }
     }

@@ -1532,4 +1532,17 @@ int dbgsom_bmu_filtered_counts(const void *workspace_dev, int64_t N, int64_t d, 
     return DBGSOM_OK;
 }
 
+/* the same copy, only queued on the stream: counts_host must be page-locked, the caller
+ * synchronises (the estimator fetches it in the round trip that brings back the epoch's results) */
+int dbgsom_bmu_filtered_counts_async(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
+                                     uint32_t *counts_host, int64_t n_counts, void *stream) {
+    DBGSOM_REQUIRE(workspace_dev && counts_host, "null pointer");
+    FilterWs f;
+    carve_filter(&f, (char *)const_cast<void *>(workspace_dev), N, d, M);
+    DBGSOM_REQUIRE(n_counts == f.nb, "n_counts must be ceil(N / 128)");
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(counts_host, f.ucount, (size_t)f.nb * 4, hipMemcpyDeviceToHost,
+                                    (hipStream_t)stream));
+    return DBGSOM_OK;
+}
+
 }  // extern "C"

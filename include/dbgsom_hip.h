@@ -149,6 +149,10 @@ int dbgsom_bmu_filtered_stage_ms(double *ms5);
 /* diagnostics: candidate-list length of every 128-sample workgroup of the last filtered call */
 int dbgsom_bmu_filtered_counts(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
                                uint32_t *counts_host, int64_t n_counts, void *stream);
+/* the same copy queued on `stream` without synchronising: counts_host must be page-locked and is
+ * valid once the caller has synchronised the stream */
+int dbgsom_bmu_filtered_counts_async(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
+                                     uint32_t *counts_host, int64_t n_counts, void *stream);
 
 /* ---- post-fit consumers of the BMU step as device reductions (N-sized arrays stay in HBM) ---- */
 
