@@ -92,51 +92,73 @@ __global__ __launch_bounds__(AT) void hist_kernel(const int64_t *__restrict__ wi
 }
 
 // ---- 2. column scan over workgroups: blk -> exclusive offsets, count[j] ----------------------
-__global__ void colscan_kernel(uint32_t *__restrict__ blk, int64_t nb, int M,
-                               uint32_t *__restrict__ count) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
+// A column is nb = N / HS entries long and its prefix is serial: CS_GROUPS threads share it (sum of
+// a group of consecutive workgroups each, prefix over the groups in LDS, then every thread rewrites
+// its group) -- 8 x fewer dependent load rounds than one thread per column.
+constexpr int CS_COLS = 32, CS_GROUPS = 8;
+__global__ __launch_bounds__(CS_COLS * CS_GROUPS) void colscan_kernel(uint32_t *__restrict__ blk,
+                                                                      int64_t nb, int M,
+                                                                      uint32_t *__restrict__ count) {
+    __shared__ uint32_t part[CS_GROUPS][CS_COLS];
+    const int c = threadIdx.x % CS_COLS, g = threadIdx.x / CS_COLS;
+    const int j = blockIdx.x * CS_COLS + c;
+    const int64_t len = (nb + CS_GROUPS - 1) / CS_GROUPS;
+    const int64_t b0 = min(nb, (int64_t)g * len), b1 = min(nb, b0 + len);
+    uint32_t sum = 0;
+    if (j < M) {
+        int64_t b = b0;
+        for (; b + 8 <= b1; b += 8) {  // 8 independent loads in flight
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = blk[(size_t)(b + u) * M + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; b < b1; ++b) sum += blk[(size_t)b * M + j];
+    }
+    part[g][c] = sum;
+    __syncthreads();
     uint32_t run = 0;
-    int64_t b = 0;
-    for (; b + 8 <= nb; b += 8) {  // 8 independent loads in flight, then the serial prefix
-        uint32_t c[8];
+    for (int u = 0; u < g; ++u) run += part[u][c];
+    if (j >= M) return;
+    if (g == CS_GROUPS - 1) count[j] = run + sum;
+    int64_t b = b0;
+    for (; b + 8 <= b1; b += 8) {
+        uint32_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = blk[(size_t)(b + u) * M + j];
+        for (int u = 0; u < 8; ++u) v[u] = blk[(size_t)(b + u) * M + j];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { blk[(size_t)(b + u) * M + j] = run; run += c[u]; }
+        for (int u = 0; u < 8; ++u) { blk[(size_t)(b + u) * M + j] = run; run += v[u]; }
     }
-    for (; b < nb; ++b) {
-        const uint32_t c = blk[(size_t)b * M + j];
+    for (; b < b1; ++b) {
+        const uint32_t v = blk[(size_t)b * M + j];
         blk[(size_t)b * M + j] = run;
-        run += c;
+        run += v;
     }
-    count[j] = run;
 }
 
 // ---- 3. exclusive scans over the M neurons (one workgroup) -----------------------------------
 __global__ __launch_bounds__(1024) void segscan_kernel(const uint32_t *__restrict__ count, int M,
                                                        uint32_t *__restrict__ seg_start,
                                                        uint32_t *__restrict__ chunk_pre) {
-    __shared__ uint32_t sa[1024], sb[1024];
-    const int t = threadIdx.x;
+    __shared__ uint32_t wa[16], wb[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int per = (M + 1023) / 1024;
-    const int lo = t * per, hi = min(M, lo + per);
+    const int lo = min(M, t * per), hi = min(M, lo + per);
     uint32_t a = 0, b = 0;
     for (int j = lo; j < hi; ++j) { a += count[j]; b += (count[j] + CH - 1) / CH; }
-    sa[t] = a; sb[t] = b;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t ra = 0, rb = 0;
-        for (int u = 0; u < 1024; ++u) {
-            const uint32_t ta = sa[u], tb = sb[u];
-            sa[u] = ra; sb[u] = rb;
-            ra += ta; rb += tb;
-        }
-        seg_start[M] = ra;
-        chunk_pre[M] = rb;
+    uint32_t ia = a, ib = b;  // inclusive scan over the wavefront, then over the 16 wavefronts
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t va = __shfl_up(ia, off, 64), vb = __shfl_up(ib, off, 64);
+        if (lane >= off) { ia += va; ib += vb; }
     }
+    if (lane == 63) { wa[wv] = ia; wb[wv] = ib; }
     __syncthreads();
-    a = sa[t]; b = sb[t];
+    uint32_t pa = 0, pb = 0;
+    for (int u = 0; u < wv; ++u) { pa += wa[u]; pb += wb[u]; }
+    if (t == 1023) { seg_start[M] = pa + ia; chunk_pre[M] = pb + ib; }
+    a = pa + ia - a; b = pb + ib - b;  // exclusive prefix of this thread's range
     for (int j = lo; j < hi; ++j) {
         seg_start[j] = a; chunk_pre[j] = b;
         a += count[j]; b += (count[j] + CH - 1) / CH;
@@ -144,41 +166,47 @@ __global__ __launch_bounds__(1024) void segscan_kernel(const uint32_t *__restric
 }
 
 // ---- 4. stable scatter of sample ids into their neuron's segment -----------------------------
-__global__ __launch_bounds__(AT) void scatter_kernel(const int64_t *__restrict__ win, int64_t N,
-                                                     int M, const uint32_t *__restrict__ blk,
-                                                     const uint32_t *__restrict__ seg_start,
-                                                     int32_t *__restrict__ order) {
+// One wavefront per workgroup of HS samples, 64 per round in sample order.  The rank of a sample
+// among the lanes holding the same winner comes from ballots over the bits of the key (peers =
+// lanes that agree in every bit), the first of them moves the neuron's write position on: no
+// search through the round's keys, no barrier between wavefronts.
+constexpr int SCW = 64;
+__global__ __launch_bounds__(SCW) void scatter_kernel(const int64_t *__restrict__ win, int64_t N,
+                                                      int M, int nbits,
+                                                      const uint32_t *__restrict__ blk,
+                                                      const uint32_t *__restrict__ seg_start,
+                                                      int32_t *__restrict__ order) {
     extern __shared__ uint32_t cnt[];  // M running write positions of this workgroup
-    __shared__ __attribute__((aligned(16))) int keys[AT];
-    const uint32_t *off = blk + (size_t)blockIdx.x * M;
-    for (int j = threadIdx.x; j < M; j += AT) cnt[j] = seg_start[j] + off[j];
+    constexpr int R = HS / SCW;
+    const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * HS;
-    const int t = threadIdx.x;
-    for (int r = 0; r < HS / AT; ++r) {
-        const int64_t i = base + r * AT + t;
-        int key = -1;
-        if (i < N) {
-            const int64_t j = win[i];
-            if (j >= 0 && j < M) key = (int)j;
-        }
-        __syncthreads();  // cnt is up to date and keys[] is no longer being read
-        keys[t] = key;
-        __syncthreads();
-        int lower = 0, higher = 0;
-        if (key >= 0) {
-            for (int u = 0; u < AT; u += 4) {  // four keys per LDS read (the reads were the cost)
-                const int4 k4 = *reinterpret_cast<const int4 *>(&keys[u]);
-                const int kk[4] = {k4.x, k4.y, k4.z, k4.w};
+    int keys[R];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    lower += (kk[e] == key && u + e < t);
-                    higher += (kk[e] == key && u + e > t);
-                }
-            }
-            order[cnt[key] + lower] = (int32_t)i;
+    for (int r = 0; r < R; ++r) {  // all of the workgroup's keys are in flight at once
+        const int64_t i = base + r * SCW + lane;
+        int64_t j = -1;
+        if (i < N) j = win[i];
+        keys[r] = (j >= 0 && j < M) ? (int)j : -1;
+    }
+    const uint32_t *off = blk + (size_t)blockIdx.x * M;
+#pragma unroll 8
+    for (int j = lane; j < M; j += SCW) cnt[j] = seg_start[j] + off[j];
+    __syncthreads();
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int key = keys[r];
+        uint64_t peers = __builtin_amdgcn_ballot_w64(key >= 0);
+        for (int b = 0; b < nbits; ++b) {
+            const bool bit = (key >> b) & 1;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(bit);
+            peers &= bit ? m : ~m;
         }
+        const uint64_t before = peers & lt;
+        if (key >= 0) order[cnt[key] + (uint32_t)__popcll(before)] = (int32_t)(base + r * SCW + lane);
         __syncthreads();  // every position of this round has been read from cnt
-        if (key >= 0 && higher == 0) cnt[key] += (uint32_t)(lower + 1);  // one thread per key
+        if (key >= 0 && before == 0) cnt[key] += (uint32_t)__popcll(peers);  // one lane per key
+        __syncthreads();
     }
 }
 
@@ -342,6 +370,12 @@ __global__ __launch_bounds__(AT) void finalize_groups_kernel(const double *__res
     }
 }
 
+static int key_bits(int64_t M) {  // bits that tell the keys 0 .. M - 1 apart
+    int b = 0;
+    while (((int64_t)1 << b) < M) ++b;
+    return b;
+}
+
 // Stable bucket order of the samples by winner, on its own (the filtered BMU search visits the
 // samples in this order).  `ws` needs bucket_sort_workspace_bytes(N, M); `order` gets N int32.
 size_t bucket_sort_workspace_bytes(int64_t N, int64_t M) {
@@ -363,11 +397,11 @@ int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order,
     const int Mi = (int)M;
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)nb), dim3(AT), (size_t)M * 4, s, idx, N, Mi, blk,
                        (int32_t *)nullptr);
-    hipLaunchKernelGGL(colscan_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, blk, nb,
-                       Mi, count);
+    hipLaunchKernelGGL(colscan_kernel, dim3((unsigned)((M + CS_COLS - 1) / CS_COLS)),
+                       dim3(CS_COLS * CS_GROUPS), 0, s, blk, nb, Mi, count);
     hipLaunchKernelGGL(segscan_kernel, dim3(1), dim3(1024), 0, s, count, Mi, seg_start, chunk_pre);
-    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nb), dim3(AT), (size_t)M * 4, s, idx, N, Mi,
-                       blk, seg_start, order);
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nb), dim3(SCW), (size_t)M * 4, s, idx, N, Mi,
+                       key_bits(M), blk, seg_start, order);
     return launch_status("bucket sort kernels");
 }
 
@@ -397,12 +431,12 @@ int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t 
 
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)w.nb), dim3(AT), (size_t)M * 4, s, idx, N, Mi,
                        w.blk, status);
-    hipLaunchKernelGGL(colscan_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, w.blk,
-                       w.nb, Mi, w.count);
+    hipLaunchKernelGGL(colscan_kernel, dim3((unsigned)((M + CS_COLS - 1) / CS_COLS)),
+                       dim3(CS_COLS * CS_GROUPS), 0, s, w.blk, w.nb, Mi, w.count);
     hipLaunchKernelGGL(segscan_kernel, dim3(1), dim3(1024), 0, s, w.count, Mi, w.seg_start,
                        w.chunk_pre);
-    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)w.nb), dim3(AT), (size_t)M * 4, s,
-                       idx, N, Mi, w.blk, w.seg_start, w.order);
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)w.nb), dim3(SCW), (size_t)M * 4, s,
+                       idx, N, Mi, key_bits(M), w.blk, w.seg_start, w.order);
 
     const size_t xe = dtype_size(x_dtype);
     const bool al16 = is_aligned(X, 16) && ((ldx * xe) % 16 == 0);
