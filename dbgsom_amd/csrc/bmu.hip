@@ -242,22 +242,24 @@ __global__ __launch_bounds__(NT, 2) void bmu_kernel(
 // squared row norms, sequential fma chain per row (same order as the oracle); rows are staged
 // through LDS so the global reads stay coalesced while each thread walks its own row.
 // ---------------------------------------------------------------------------------------------
-// Two shapes of the same kernel: 128 rows x 32 features per staged tile for the sample matrix
-// (one thread per row walks the chain), 16 rows x 256 features for the small prototype matrix
-// (more workgroups, fewer dependent load rounds: it is latency-bound at M ~ 1000).
-constexpr int NORM_THREADS = 128;
-
-template <typename T, int NR, int NK>
-__global__ __launch_bounds__(NORM_THREADS) void row_sqnorms_kernel(const T *__restrict__ A,
-                                                                   int64_t rows, int d, int64_t ld,
-                                                                   double *__restrict__ out) {
+// Two shapes of the same kernel: 128 rows x 32 features per staged tile, 128 threads, for the
+// sample matrix (one thread per row walks the chain); 8 rows x 1024 features, 512 threads, for the
+// small prototype matrix, which is latency-bound at M ~ 1000: more workgroups, and a row of up to
+// 1024 features is staged in ONE round of loads that are all in flight at once (the 16 x 256
+// shape before it spent 38 us per epoch in four rounds of four dependent load batches).
+template <typename T, int NR, int NK, int NTH>
+__global__ __launch_bounds__(NTH) void row_sqnorms_kernel(const T *__restrict__ A,
+                                                          int64_t rows, int d, int64_t ld,
+                                                          double *__restrict__ out) {
+    constexpr int NORM_THREADS = NTH;
+    constexpr int LOAD_UNROLL = NR * NK / NTH < 16 ? NR * NK / NTH : 16;
     __shared__ double tile[NR][NK + 1];
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * NR;
     double acc = 0.0;
     for (int k0 = 0; k0 < d; k0 += NK) {
         __syncthreads();
-#pragma unroll 8
+#pragma clang loop unroll_count(LOAD_UNROLL)
         for (int e = tid; e < NR * NK; e += NORM_THREADS) {
             const int r = e / NK, c = e % NK;  // consecutive threads -> consecutive features
             const int64_t row = r0 + r;
@@ -301,20 +303,19 @@ int launch_row_sqnorms(const void *A, int dtype, int64_t rows, int64_t d, int64_
     if (rows == 0) return DBGSOM_OK;
     DBGSOM_REQUIRE(A && out, "null pointer");
     const bool small = rows <= 16384;
-    const int nr = small ? 16 : 128;
+    const int nr = small ? 8 : 128;
     const int64_t nb = (rows + nr - 1) / nr;
     DBGSOM_REQUIRE(nb <= 0x7fffffff, "too many rows");
-    dim3 grid((unsigned)nb), block(NORM_THREADS);
-    if (dtype == DBGSOM_F32) {
-        if (small) hipLaunchKernelGGL((row_sqnorms_kernel<float, 16, 256>), grid, block, 0, s, (const float *)A, rows, (int)d, ld, out);
-        else hipLaunchKernelGGL((row_sqnorms_kernel<float, 128, 32>), grid, block, 0, s, (const float *)A, rows, (int)d, ld, out);
-    } else if (dtype == DBGSOM_F64) {
-        if (small) hipLaunchKernelGGL((row_sqnorms_kernel<double, 16, 256>), grid, block, 0, s, (const double *)A, rows, (int)d, ld, out);
-        else hipLaunchKernelGGL((row_sqnorms_kernel<double, 128, 32>), grid, block, 0, s, (const double *)A, rows, (int)d, ld, out);
-    } else {
-        if (small) hipLaunchKernelGGL((row_sqnorms_kernel<bf16_t, 16, 256>), grid, block, 0, s, (const bf16_t *)A, rows, (int)d, ld, out);
-        else hipLaunchKernelGGL((row_sqnorms_kernel<bf16_t, 128, 32>), grid, block, 0, s, (const bf16_t *)A, rows, (int)d, ld, out);
-    }
+    dim3 grid((unsigned)nb);
+#define DBGSOM_NORMS(T)                                                                            \
+    do {                                                                                           \
+        if (small) hipLaunchKernelGGL((row_sqnorms_kernel<T, 8, 1024, 512>), grid, dim3(512), 0, s, (const T *)A, rows, (int)d, ld, out); \
+        else hipLaunchKernelGGL((row_sqnorms_kernel<T, 128, 32, 128>), grid, dim3(128), 0, s, (const T *)A, rows, (int)d, ld, out); \
+    } while (0)
+    if (dtype == DBGSOM_F32) DBGSOM_NORMS(float);
+    else if (dtype == DBGSOM_F64) DBGSOM_NORMS(double);
+    else DBGSOM_NORMS(bf16_t);
+#undef DBGSOM_NORMS
     return launch_status("row_sqnorms_kernel");
 }
 
