@@ -31,6 +31,8 @@ constexpr int FKT = 64;           // bytes (= features) per plane row per LDS st
 constexpr int FNT = 512;          // threads per sweep workgroup (8 wavefronts)
 constexpr int FSTAGES = 3;
 constexpr int PREPASS_KTILES = 3;  // k-tiles the seed pre-pass samples (tile_select_kernel picks them)
+constexpr int SCHED_BINS = 16;     // launch-order bins of the exact stage (section 2b)
+constexpr int SCHED_CTR = 2 * SCHED_BINS + 8;  // bin counts | cursors | [start, n] of classes 3, 2, 1
 constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
 #ifndef SUBSET_EXPERIMENT
 // Diagnostic builds of this file (never the shipped library): -DSUBSET_EXPERIMENT=<bits> /
@@ -241,9 +243,11 @@ __global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict_
                                                        double *__restrict__ yy_sub,
                                                        double tscale, double *__restrict__ ictab,
                                                        double *__restrict__ yctab,
-                                                       double *__restrict__ summary) {
+                                                       double *__restrict__ summary,
+                                                       uint32_t *__restrict__ sched_ctr) {
     __shared__ double r0[1024], r1[1024], r2[1024];
     const int t = threadIdx.x;
+    if (t < SCHED_CTR) sched_ctr[t] = 0u;  // bin counts / cursors / ranges of the exact stage's schedule
     double a = 0.0, b = 0.0, c = 0.0;
     for (int j = t; j < Mpad; j += 1024) {
         const long js = (long)j * stride;  // j-th entry of the strided tables
@@ -949,6 +953,59 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     }
 }
 
+// ---- 2b. launch order of the exact stage ---------------------------------------------------------
+// The workgroups of the exact stage differ in length (one step per 16 JTL list entries) and sit in
+// the grid in sample order: a two-step list that starts in the last round of resident workgroups
+// keeps a mostly idle chip waiting for a whole extra step (C4: ~0.25 ms of a 1.3 ms stage).  The
+// workgroup ids are therefore bucketed into SCHED_BINS bins -- class 3 by steps, longest first
+// (bins 0 .. 13), then class 2 (14), then class 1 (15) -- and every class kernel walks its range of
+// that schedule.  Within a bin the order is whatever the atomics give (blocks of 256 consecutive
+// workgroups stay together): the schedule only decides WHEN a workgroup runs, never what it writes.
+__device__ __forceinline__ int sched_bin(uint32_t c) {
+    if (c <= 16u) return 15;
+    if (c <= 32u) return 14;
+    const int steps = (int)((c + 47u) / 48u);
+    return steps >= 14 ? 0 : 14 - steps;
+}
+__global__ __launch_bounds__(256) void sched_count_kernel(const uint32_t *__restrict__ ucount, int nb,
+                                                          uint32_t *__restrict__ ctr) {
+    __shared__ uint32_t h[SCHED_BINS];
+    if (threadIdx.x < SCHED_BINS) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < nb) atomicAdd(&h[sched_bin(ucount[b])], 1u);
+    __syncthreads();
+    if (threadIdx.x < SCHED_BINS && h[threadIdx.x]) atomicAdd(&ctr[threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void sched_fill_kernel(const uint32_t *__restrict__ ucount, int nb,
+                                                         uint32_t *__restrict__ ctr,
+                                                         int32_t *__restrict__ sched) {
+    __shared__ uint32_t h[SCHED_BINS], base[SCHED_BINS];
+    if (threadIdx.x < SCHED_BINS) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    int bin = -1;
+    uint32_t r = 0;
+    if (b < nb) {
+        bin = sched_bin(ucount[b]);
+        r = atomicAdd(&h[bin], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < SCHED_BINS) {
+        uint32_t off = 0;
+        for (int u = 0; u < (int)threadIdx.x; ++u) off += ctr[u];
+        base[threadIdx.x] = off + (h[threadIdx.x] ? atomicAdd(&ctr[SCHED_BINS + threadIdx.x], h[threadIdx.x]) : 0u);
+        if (blockIdx.x == 0) {  // the class ranges, for the class kernels
+            uint32_t *range = ctr + 2 * SCHED_BINS;
+            if (threadIdx.x == 0) range[0] = 0u;
+            if (threadIdx.x == 14) { range[1] = off; range[2] = off; range[3] = ctr[14]; }
+            if (threadIdx.x == 15) { range[4] = off; range[5] = ctr[15]; }
+        }
+    }
+    __syncthreads();
+    if (bin >= 0) sched[base[bin] + r] = b;
+}
+
 // ---- 3. exact arg-min over the marked prototypes (float64 MFMA on gathered rows) -----------------
 // 128 gathered samples x SJ = 16 JTL listed prototypes per step; 4 wavefronts x 32 samples,
 // 3-stage LDS-DMA ring.  Three instantiations (JTL = 1, 2, 3) are launched back to back, each
@@ -960,7 +1017,8 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
     const double *__restrict__ W, int M, const double *__restrict__ ww,
     const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
-    const uint32_t *__restrict__ ucount, int round_f32, int64_t *__restrict__ idx_out,
+    const uint32_t *__restrict__ ucount, const int32_t *__restrict__ sched,
+    const uint32_t *__restrict__ sched_range, int round_f32, int64_t *__restrict__ idx_out,
     double *__restrict__ dist_out) {
     constexpr int SJ = 16 * JTL;
     // X tile: 128 rows x KT values, float32 (64-byte rows) or float64 (128-byte rows, laid out like W)
@@ -979,15 +1037,18 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     const uint64_t r_start = __builtin_amdgcn_s_memrealtime();
     uint64_t t_loop = 0, t_loop_end = 0;
 #endif
-    const int cnt = (int)ucount[blockIdx.x];
-    if (JTL == 1 ? (cnt > 16) : (JTL == 2 ? (cnt <= 16 || cnt > 32) : (cnt <= 32))) return;
+    // this class's slice of the schedule (2b): entry blockIdx.x of it, nothing beyond its end
+    const uint32_t *range = sched_range + 2 * (3 - JTL);
+    if (blockIdx.x >= range[1]) return;
+    const int wg = sched[range[0] + blockIdx.x];
+    const int cnt = (int)ucount[wg];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 4 waves x 32 samples
     const int lr = lane & 15, lq = lane >> 4;
-    const int64_t p0 = (int64_t)blockIdx.x * 128;
-    const uint16_t *list = ulist + (size_t)blockIdx.x * ulist_stride;
+    const int64_t p0 = (int64_t)wg * 128;
+    const uint16_t *list = ulist + (size_t)wg * ulist_stride;
 
     double xi[2];
     int64_t isamp[2];
@@ -1238,6 +1299,8 @@ struct FilterWs {
     int32_t *kt_sel;     // SW_MAX_KT
     uint16_t *ulist;
     uint32_t *ucount;
+    int32_t *sched;       // nb   workgroup ids in launch order of the exact stage
+    uint32_t *sched_ctr;  // SCHED_CTR counters of that schedule
     int64_t *seed;     // N   arg-min of the coarse pre-pass (when the caller has no previous winners)
     int32_t *order;    // N   bucket order of the samples by seed
     void *sort_ws;
@@ -1257,7 +1320,9 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
     const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
+    const size_t o16 = take((size_t)nb * 4), o17 = take((size_t)SCHED_CTR * 4);
     if (f) {
+        f->sched = (int32_t *)(base + o16); f->sched_ctr = (uint32_t *)(base + o17);
         f->wt = (int8_t *)(base + ow); f->wt_sub = (int8_t *)(base + ows);
         f->wscale = (double *)(base + osc); f->wl1 = (double *)(base + ol1);
         f->ctab = (double *)(base + o0); f->yypad = (double *)(base + o1);
@@ -1432,7 +1497,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                        f.wt_sub, f.wscale, f.wl1, f.yy_part);
     hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.wscale, f.wl1, ww_dev, f.yy_part, (int)M,
                        (int)f.Mpad, seed_stride, f.ctab, f.yypad, f.ctab_sub, f.yy_sub,
-                       sweep_tscale(sweep_planes), f.ictab, f.yctab, f.summary);
+                       sweep_tscale(sweep_planes), f.ictab, f.yctab, f.summary, f.sched_ctr);
     g_timer.mark(1, s);
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
@@ -1476,6 +1541,10 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                            f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
                            (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr);
     g_timer.mark(4, s);
+    hipLaunchKernelGGL(sched_count_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount,
+                       (int)f.nb, f.sched_ctr);
+    hipLaunchKernelGGL(sched_fill_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount,
+                       (int)f.nb, f.sched_ctr, f.sched);
     // the three list-length classes write disjoint samples: they run side by side (classes 1 and 2
     // on a second stream forked from the caller's), so that the tail of one launch -- a few long
     // lists on a mostly idle chip -- overlaps the others
@@ -1491,11 +1560,11 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         if (x_dtype == DBGSOM_F32)                                                                \
             hipLaunchKernelGGL((subset_exact_kernel<float, JTL>), dim3((unsigned)f.nb), dim3(NT), 0, STREAM, \
                                (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
-                               order_dev, f.ulist, (int)f.Mpad, f.ucount, round_f32, idx_dev, dist_dev); \
+                               order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
         else                                                                                      \
             hipLaunchKernelGGL((subset_exact_kernel<double, JTL>), dim3((unsigned)f.nb), dim3(NT), 0, STREAM, \
                                (const double *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
-                               order_dev, f.ulist, (int)f.Mpad, f.ucount, round_f32, idx_dev, dist_dev); \
+                               order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
     } while (0)
     DBGSOM_SUBSET(3, s);
     DBGSOM_SUBSET(2, s2);
