@@ -953,6 +953,380 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     }
 }
 
+// ---- 2a'. the one-product candidate sweep as 4-wavefront workgroups ---------------------------
+// Same arithmetic, bound, marking rule and outputs as sweep_i8_kernel<0, 1, JT>; another shape of
+// the same work: 256 threads = 4 wavefronts as 2 (samples) x 2 (prototypes), workgroup tile 128
+// samples x 256 prototypes, wavefront tile 64 x 128.  The ring stages are 24 KB and ONE set of chunk
+// tables is kept, 79.5 KB of LDS in all: TWO workgroups share a CU, so the two wavefronts of a SIMD
+// belong to different workgroups -- they are not tied to the same barrier, and one workgroup's
+// prologue, chunk epilogues and list compaction run under the other's products.
+constexpr int S4_NT = 256;
+struct Sweep4Lds {
+    static constexpr int JT = 4, BJ = 256;
+    static constexpr int X_BYTES = 128 * FKT, W_BYTES = BJ * FKT, STAGE = X_BYTES + W_BYTES;  // 8 + 16 KB
+    static constexpr int TAB = BJ * 8;
+    static constexpr int OFF_TAB = FSTAGES * STAGE;
+    static constexpr int OFF_THR = OFF_TAB + 2 * TAB;
+    static constexpr int OFF_PREV = OFF_THR + 128 * 8;
+    static constexpr int OFF_MASK = OFF_PREV + 128 * 4;
+    static constexpr int OFF_MISC = OFF_MASK + (SW_MAX_M + 31) / 32 * 4;
+    static constexpr int BYTES = OFF_MISC + 16;
+};
+static_assert(Sweep4Lds::BYTES <= 81920, "two workgroups per CU");
+
+__global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
+    const int8_t *__restrict__ xplanes, const double *__restrict__ sx,
+    const double *__restrict__ l1x, const double *__restrict__ xx, int64_t N, int d, int dpad,
+    const int8_t *__restrict__ wplanes, const double *__restrict__ ytab_g,
+    const double *__restrict__ ctab_g, const double *__restrict__ yraw,
+    const double *__restrict__ craw, const double *__restrict__ summary, int M,
+    const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
+    uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, int w_rows) {
+    using L = Sweep4Lds;
+    constexpr int JT = L::JT, BJ = L::BJ, PLANES = 1;
+    constexpr int DMA_TILE = 6;  // per wave and tile: 2 KiB of X rows, 4 KiB of W rows
+    __shared__ __attribute__((aligned(16))) char smem[L::BYTES];
+    double *thr_s = reinterpret_cast<double *>(smem + L::OFF_THR);
+    int *prev_s = reinterpret_cast<int *>(smem + L::OFF_PREV);
+    uint32_t *mask = reinterpret_cast<uint32_t *>(smem + L::OFF_MASK);
+    int *misc = reinterpret_cast<int *>(smem + L::OFF_MISC);
+    const double *ytab = reinterpret_cast<const double *>(smem + L::OFF_TAB);
+    const double *ctb = ytab + BJ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int lc = lane & 31, lh = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * 128;
+    const int nwords = (M + 31) / 32;
+
+    auto sample_at = [&](int64_t p) -> int64_t { return (int64_t)order[p]; };
+    // every thread's own loads first (see sweep_i8_kernel)
+    int64_t i_dr[2];
+    int dc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {  // DMA: wave w loads X rows 32 w .. 32 w + 31, 16 per instruction
+        const int r = 16 * (2 * wave + u) + (lane >> 2);
+        const int64_t xpos = (p0 + r < N) ? (p0 + r) : (N - 1);
+        i_dr[u] = sample_at(xpos);
+        dc[u] = (lane & 3) ^ ((r >> 2) & 3);
+    }
+    int64_t i_il[2];
+    double s_i[2], l1_i[2], xx_i[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int64_t p = p0 + wi * 64 + it * 32 + lc;
+        i_il[it] = sample_at(p < N ? p : N - 1);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        s_i[it] = sx[i_il[it]];
+        l1_i[it] = l1x[i_il[it]];
+        xx_i[it] = xx[i_il[it]];
+    }
+    for (int w = tid; w < nwords; w += S4_NT) mask[w] = 0u;
+    if (tid < 128) {
+        const int64_t p = p0 + tid;
+        int pj = -1;
+        if (p < N) pj = (int)prev[sample_at(p)];
+        prev_s[tid] = (pj >= 0 && pj < M) ? pj : -1;
+        thr_s[tid] = (p < N) ? -INFINITY : INFINITY;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int a = prev_s[lane], b = prev_s[lane + 64];
+        int lo = min(a >= 0 ? a : 0x7fffffff, b >= 0 ? b : 0x7fffffff), hi = max(a, b);
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            lo = min(lo, __shfl_xor(lo, m, 64));
+            hi = max(hi, __shfl_xor(hi, m, 64));
+        }
+        if (lane == 0) {
+            misc[0] = (hi >= 0) ? lo : 0;
+            misc[1] = hi;
+        }
+    }
+    __syncthreads();
+    const int jlo = __builtin_amdgcn_readfirstlane(misc[0]);
+    const int jhi = __builtin_amdgcn_readfirstlane(misc[1]);
+    if (jlo / BJ != jhi / BJ) {  // seeds in a later chunk: their bound up front (2 threads per sample)
+        const int il = tid >> 1, q = tid & 1;
+        const int64_t p = p0 + il;
+        const int pj = prev_s[il];
+        const bool need = p < N && pj >= 0 && pj / BJ != jlo / BJ;
+        int a0 = 0;
+        const int64_t i = sample_at(p < N ? p : N - 1);
+        if (need) {
+            const int8_t *xr = xplanes + (size_t)i * dpad;
+            const int wsw = (pj >> 2) & 3;
+            for (int ch = q; ch < dpad / 16; ch += 2) {
+                const int8_t *wr = wplanes + ((size_t)(ch >> 2) * w_rows + pj) * FKT + (((ch & 3) ^ wsw) << 4);
+                const v4i_t xv = *reinterpret_cast<const v4i_t *>(xr + ch * 16);
+                const v4i_t wv = *reinterpret_cast<const v4i_t *>(wr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a0 = __builtin_amdgcn_sdot4(xv[e], wv[e], a0, false);
+            }
+        }
+        a0 += __shfl_xor(a0, 1, 64);
+        if (need && q == 0) {
+            const double T = sweep_T<PLANES>(a0, 0, 0);
+            const double sv = sx[i], xv2 = xx[i];
+            const double e2 = 2.0 * filter_eps(sv, l1x[i], xv2, summary[0], summary[1], summary[2], d, PLANES);
+            thr_s[il] = (sv * (craw[pj] * T) - yraw[pj]) - e2;
+        }
+        __syncthreads();
+    }
+
+    double eps2_i[2], A_i[2];
+    const double l1w_max = summary[0], t_max = summary[1], yy_max = summary[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        eps2_i[it] = 2.0 * filter_eps(s_i[it], l1_i[it], xx_i[it], l1w_max, t_max, yy_max, d, PLANES);
+        A_i[it] = thr_s[wi * 64 + it * 32 + lc];
+    }
+
+    const int8_t *xsrc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) xsrc[u] = xplanes + (size_t)i_dr[u] * dpad + dc[u] * 16;
+    const int nkt = dpad / FKT;  // >= 2 (filter_dpad)
+    const int nchunk = (M + BJ - 1) / BJ;
+    const int ntile = nkt * nchunk;
+    const int c0 = jlo / BJ;
+
+    int i_kt = 0, i_chunk = c0, i_stage = 0;
+    const uint32_t lane16 = 16u * lane;
+    // the 6 LDS-DMA instructions of a tile: X rows 16 (2 w + u) .. (ops 0, 1), W rows
+    // 16 (w + 4 v) .. of the chunk (ops 2 + v); ops [lo, hi) are issued, hi == DMA_TILE advances
+    auto issue_ops = [&](int lo, int hi) {
+        char *stage = smem + i_stage;
+        const int k0 = i_kt * FKT;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (u >= lo && u < hi) fdma16(xsrc[u] + k0, stage + 1024 * (2 * wave + u));
+        const int8_t *wsrc = wplanes + ((size_t)i_kt * w_rows + (size_t)i_chunk * BJ) * FKT + lane16;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (2 + v >= lo && 2 + v < hi)
+                fdma16(wsrc + 1024 * (wave + 4 * v), stage + L::X_BYTES + 1024 * (wave + 4 * v));
+        if (hi == DMA_TILE) {
+            i_stage = (i_stage == (FSTAGES - 1) * L::STAGE) ? 0 : i_stage + L::STAGE;
+            if (++i_kt == nkt) {
+                i_kt = 0;
+                i_chunk = (i_chunk + 1 == nchunk) ? 0 : i_chunk + 1;
+            }
+        }
+    };
+    // the chunk tables (4 pieces of 1 KiB: |w|^2 / c halves, 1 / c halves), one piece per wave
+    auto issue_tables = [&](int chunk) {
+        const int half = wave & 1;
+        const int j2 = chunk * BJ + 128 * half + 2 * lane;  // tables are padded to whole 512-entry chunks
+        char *tab = smem + L::OFF_TAB;
+        if (wave >= 2) fdma16(ctab_g + j2, tab + L::TAB + 1024 * half);
+        else fdma16(ytab_g + j2, tab + 1024 * half);
+    };
+
+    int xoff[2], woff[JT];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = wi * 64 + it * 32 + lc;
+        xoff[it] = r * FKT + ((lh ^ ((r >> 2) & 3)) * 16);
+    }
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        const int r = wj * 32 * JT + jt * 32 + lc;
+        woff[jt] = L::X_BYTES + r * FKT + ((lh ^ ((r >> 2) & 3)) * 16);
+    }
+    struct Frags { v4i_t x[2], w[JT]; };
+    auto load_frags = [&](int stage_off, int ks, Frags &f) {
+        const char *stage = smem + stage_off;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+            f.w[jt] = *reinterpret_cast<const v4i_t *>(stage + (woff[jt] ^ (ks * 32)));
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+            f.x[it] = *reinterpret_cast<const v4i_t *>(stage + (xoff[it] ^ (ks * 32)));
+    };
+    auto touch_frags = [&](const Frags &f) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) asm volatile("" ::"v"(f.w[jt]));
+#pragma unroll
+        for (int it = 0; it < 2; ++it) asm volatile("" ::"v"(f.x[it]));
+    };
+    v16i_t acc[JT][2];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[jt][it][r] = 0;
+    auto products = [&](const Frags &f, auto between) {
+#pragma unroll
+        for (int jh = 0; jh < JT; jh += 2) {
+#pragma unroll
+            for (int jt = jh; jt < jh + 2; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+                    acc[jt][it] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[jt], f.x[it], acc[jt][it], 0, 0, 0);
+            between(jh >> 1);
+        }
+    };
+    auto wait_vm = [&](int n) {  // s_waitcnt vmcnt needs an immediate
+        if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n == DMA_TILE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_TILE) : "memory");
+        else if (n == DMA_TILE + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_TILE + 1) : "memory");
+        else if (n == 2 * DMA_TILE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_TILE + 1) : "memory");
+    };
+
+    // ---- pipeline: as sweep_i8_kernel (tile t in stage t % 3, one barrier per tile) ---------------
+    issue_tables(c0);  // first in the queue: complete with the first tile
+    const int n_pre = ntile < 3 ? ntile : 3;
+    for (int u = 0; u < n_pre; ++u) issue_ops(0, DMA_TILE);
+    wait_vm(ntile > 2 ? 2 * DMA_TILE : (ntile > 1 ? DMA_TILE : 0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    Frags f0, f1;
+    load_frags(0, 0, f0);
+    int r_kt = 0, r_chunk = c0, r_stage = 0;
+    bool tab_pending = false;  // a table DMA was issued in the previous tile's second half
+    for (int t = 0; t < ntile; ++t) {
+        const int r_next = (r_stage == (FSTAGES - 1) * L::STAGE) ? 0 : r_stage + L::STAGE;
+        const bool back_now = t >= 1 && t + 2 < ntile;
+        products(f0, [&](int g) {
+            if (g == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(r_stage, 1, f1);
+                touch_frags(f0);
+                if (back_now) issue_ops(DMA_TILE / 2, DMA_TILE);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        // own DMAs of tile t + 1 landed: what may stay in flight is tile t + 2 (and the table piece
+        // issued behind the previous barrier, which sits between tiles t + 2 and t + 3 in the queue)
+        if (t + 2 < ntile) wait_vm(DMA_TILE + (tab_pending ? 1 : 0));
+        else wait_vm(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        tab_pending = false;
+        const bool front_now = t + 3 < ntile;
+        products(f1, [&](int g) {
+            if (g == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (r_kt != nkt - 1) load_frags(r_next, 0, f0);
+                touch_frags(f1);
+                // every wave is past the previous chunk's epilogue here: the table set may be
+                // replaced by this chunk's
+                if (r_kt == 0 && t > 0) { issue_tables(r_chunk); tab_pending = true; }
+                if (front_now) issue_ops(0, DMA_TILE / 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+
+        if (r_kt == nkt - 1) {
+            // the table pieces of this chunk: own piece landed (at most the 9 DMAs issued behind it
+            // are in flight), then everybody's
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int jc = r_chunk * BJ;
+            const bool has_prev = (jc <= jhi) && (jc + BJ - 1 >= jlo);
+            int jl0 = wj * 32 * JT + 4 * lh;
+            asm volatile("" : "+v"(jl0));
+            if (has_prev) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    int a0s = 0, jls = -1;
+                    const int want = prev_s[wi * 64 + it * 32 + lc] - jc;
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int jl = jl0 + jt * 32 + (r & 3) + 8 * (r >> 2);
+                            const bool sel = jl == want;
+                            a0s = sel ? acc[jt][it][r] : a0s;
+                            jls = sel ? jl : jls;
+                        }
+                    if (jls >= 0)
+                        thr_s[wi * 64 + it * 32 + lc] =
+                            (s_i[it] * (craw[jc + jls] * sweep_T<PLANES>(a0s, 0, 0)) - yraw[jc + jls]) - eps2_i[it];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 2; ++it) A_i[it] = thr_s[wi * 64 + it * 32 + lc];
+            }
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    double y4[4], c4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        y4[i] = ytab[jl0 + jt * 32 + 8 * g + i];
+                        c4[i] = ctb[jl0 + jt * 32 + 8 * g + i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * g + i;
+                        uint64_t pass = 0;
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            const double Tp = (double)acc[jt][it][r];
+                            pass |= __builtin_amdgcn_ballot_w64((A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp);
+                        }
+                        word |= (uint32_t)((uint32_t)pass != 0u) << (8 * g + i);
+                        word |= (uint32_t)((uint32_t)(pass >> 32) != 0u) << (4 + 8 * g + i);
+                    }
+                }
+                const int wbase = jc + wj * 32 * JT + jt * 32;
+                if (wbase < M) {
+                    if (M - wbase < 32) word &= (1u << (M - wbase)) - 1u;
+                    if (word != 0u && lane == 0) atomicOr(&mask[wbase >> 5], word);
+                }
+            }
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[jt][it][r] = 0;
+            r_kt = 0;
+            r_chunk = (r_chunk + 1 == nchunk) ? 0 : r_chunk + 1;
+            load_frags(r_next, 0, f0);
+        } else {
+            ++r_kt;
+        }
+        r_stage = r_next;
+    }
+
+    __syncthreads();
+    if (wave == 0) {  // compact the marked prototypes, ascending
+        uint32_t base = 0;
+        uint16_t *out = ulist + (size_t)blockIdx.x * ulist_stride;
+        for (int w0 = 0; w0 < nwords; w0 += 64) {
+            const int w = w0 + lane;
+            uint32_t bits = (w < nwords) ? mask[w] : 0u;
+            const uint32_t cnt = __popc(bits);
+            uint32_t pre = cnt;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(pre, off, 64);
+                if (lane >= off) pre += v;
+            }
+            uint32_t pos = base + pre - cnt;
+            while (bits) {
+                const int b = __ffs(bits) - 1;
+                bits &= bits - 1;
+                out[pos++] = (uint16_t)(w * 32 + b);
+            }
+            base += __shfl(pre, 63, 64);
+        }
+        if (lane == 0) ucount[blockIdx.x] = base;
+    }
+}
+
 // ---- 2b. launch order of the exact stage ---------------------------------------------------------
 // The workgroups of the exact stage differ in length (one step per 16 JTL list entries) and sit in
 // the grid in sample order: a two-step list that starts in the last round of resident workgroups
@@ -1528,7 +1902,17 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                        xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab, f.yypad,    \
                        f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad,     \
                        f.ucount, (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr)
-    if (sweep_planes == 1) {  // one digit product: 128 x 512 tile (128 x 256 for small maps)
+    static const int sweep_shape = [] {  // DBGSOM_SWEEP_SHAPE=8: the 8-wavefront one-product sweep
+        const char *e = getenv("DBGSOM_SWEEP_SHAPE");
+        return e ? atoi(e) : 4;
+    }();
+    if (sweep_planes == 1 && sweep_shape == 4 && order_dev) {
+        // one digit product, 4-wavefront workgroups (128 x 256 tile), two of them per CU
+        hipLaunchKernelGGL(sweep4_i8_kernel, dim3((unsigned)f.nb), dim3(S4_NT), 0, s, xb.planes, xb.scale,
+                           xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab, f.yypad, f.ctab,
+                           f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
+                           (int)f.Mpad);
+    } else if (sweep_planes == 1) {  // one digit product: 128 x 512 tile (128 x 256 for small maps)
         if (M > 256) DBGSOM_SWEEP(1, 4); else DBGSOM_SWEEP(1, 2);
     } else if (sweep_planes == 3)
         hipLaunchKernelGGL((sweep_i8_kernel<0, 3, 1>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
