@@ -49,6 +49,7 @@ I8_MFMA_PEAK_TOPS = 5033.0   # 256 x 4 x 2.4 GHz x 65536 op / 32 cycles (v_mfma_
 # (FETCH_SIZE x 2 per the gfx950 correction); not measurable inside this process.  Keyed by the
 # number of digit planes the sweep reads (1 -> sweep_i8_kernel<0,1,4>, 2 -> <0,2,2>, 3 -> <0,3,1>)
 SWEEP_TRAFFIC_C4_BYTES = {1: 1.99e9, 2: 7.90e9, 3: 2.42e10}
+SWEEP4_TRAFFIC_C4_BYTES = 4.15e9  # sweep4_i8_kernel (one product, 4-wavefront workgroups): plane 0 of X once per 256 prototypes
 SWEEP_KERNEL = {1: "sweep_i8_kernel<0,1,4>", 2: "sweep_i8_kernel<0,2,2>", 3: "sweep_i8_kernel<0,3,1>"}
 SWEEP_PRODUCTS = {1: 1, 2: 3, 3: 6}   # int8 digit products kept per (sample, prototype, k)
 
@@ -326,12 +327,17 @@ def main():
         else:
             dpad = (d + 63) // 64 * 64
             planes = int(stage.get("sweep_planes", 2))
+            from dbgsom_amd import _native
+
+            small = planes == 1 and _native.load().dbgsom_sweep_shape(M, d) == 4
+            kernel = "sweep4_i8_kernel" if small else SWEEP_KERNEL[planes]
+            traffic = SWEEP4_TRAFFIC_C4_BYTES if small else SWEEP_TRAFFIC_C4_BYTES[planes]
             ops = 2.0 * n_gpu * M * dpad * SWEEP_PRODUCTS[planes]  # int8 ops the sweep executes
             ach = ops / (stage["sweep"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": SWEEP_KERNEL[planes], "dtype": "i8",
+            roof = {"bound": "mfma", "kernel": kernel, "dtype": "i8",
                     "achieved": ach, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                     "frac": ach / I8_MFMA_PEAK_TOPS,
-                    "traffic": SWEEP_TRAFFIC_C4_BYTES[planes] if args.workload == "c4" and
+                    "traffic": traffic if args.workload == "c4" and
                     n_gpu == WORKLOADS["c4"][0] else None,
                     "kernel_ms": stage["sweep"], "digit_products": SWEEP_PRODUCTS[planes],
                     "algorithmic_equiv_TFLOPs": flops / (stage["sweep"] * 1e-3) / 1e12}

@@ -43,6 +43,7 @@ SIGNATURES = {
                                   _ci, _ci, _ci, _vp, _vp, _vp, _sz, _vp]),
     "dbgsom_bmu_filtered_counts": (_ci, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "dbgsom_bmu_filtered_counts_async": (_ci, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "dbgsom_sweep_shape": (_ci, [_i64, _i64]),
     "dbgsom_filter_timing": (_ci, [_ci]),
     "dbgsom_bmu_filtered_stage_ms": (_ci, [_vp]),
     "dbgsom_sum_workspace_bytes": (_sz, []),

@@ -1809,6 +1809,19 @@ size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M) {
     return carve_filter(nullptr, nullptr, N, d, M);
 }
 
+/* wavefronts per workgroup of the one-product candidate sweep for this map: 4 (128 x 256 tile, two
+ * workgroups per CU) or 8 (128 x 512 tile, one per CU); see the cost model at the launch */
+int dbgsom_sweep_shape(int64_t M, int64_t d) {
+    static const int forced = [] {  // DBGSOM_SWEEP_SHAPE=4 / 8 forces one
+        const char *e = getenv("DBGSOM_SWEEP_SHAPE");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 4 || forced == 8) return forced;
+    if (M < 1 || d < 1) return 8;
+    const double nkt = (double)(filter_dpad(d) / FKT), c4 = (double)((M + 255) / 256), c8 = (double)((M + 511) / 512);
+    return (c4 * nkt * 1766.0 < nkt * c8 * 2300.0 + 37000.0) ? 4 : 8;
+}
+
 int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                         const double *xx_dev, const void *xplanes_dev, const double *W_dev,
                         int64_t M, const double *ww_dev, const int64_t *prev_idx_dev,
@@ -1902,10 +1915,13 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                        xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab, f.yypad,    \
                        f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad,     \
                        f.ucount, (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr)
-    static const int sweep_shape = [] {  // DBGSOM_SWEEP_SHAPE=8: the 8-wavefront one-product sweep
-        const char *e = getenv("DBGSOM_SWEEP_SHAPE");
-        return e ? atoi(e) : 4;
-    }();
+    // One digit product: 8-wavefront workgroups (128 x 512 tile, one per CU) or 4-wavefront ones
+    // (128 x 256 tile, two per CU).  The small shape overlaps what the big one serialises (its tile
+    // loop runs ~10-17 % faster per unit of work and the per-workgroup overhead hides), but it reads
+    // the X plane once per 256 prototypes instead of once per 512 and that gather stream tops out
+    // near 2.9 TB/s.  Cost model from the measured C2-C5 launches, in cycles per workgroup:
+    // big shape nkt * chunks * 2300 + 37000; small shape bound by bytes = chunks * nkt * 1766.
+    const int sweep_shape = dbgsom_sweep_shape(M, d);
     if (sweep_planes == 1 && sweep_shape == 4 && order_dev) {
         // one digit product, 4-wavefront workgroups (128 x 256 tile), two of them per CU
         hipLaunchKernelGGL(sweep4_i8_kernel, dim3((unsigned)f.nb), dim3(S4_NT), 0, s, xb.planes, xb.scale,

@@ -146,6 +146,9 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
  * ms5 = [slice W + tables, coarse pre-pass, bucket sort, int8 sweep, exact search on candidates] */
 int dbgsom_filter_timing(int enable);
 int dbgsom_bmu_filtered_stage_ms(double *ms5);
+/* diagnostics: which shape of the one-product candidate sweep a map of M prototypes x d features
+ * gets: 4 = sweep4_i8_kernel (4-wavefront workgroups, two per CU), 8 = sweep_i8_kernel<0,1,JT> */
+int dbgsom_sweep_shape(int64_t M, int64_t d);
 /* diagnostics: candidate-list length of every 128-sample workgroup of the last filtered call */
 int dbgsom_bmu_filtered_counts(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
                                uint32_t *counts_host, int64_t n_counts, void *stream);
