@@ -327,6 +327,12 @@ __device__ __forceinline__ void fdma16(const void *src, void *lds_dst) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_dst, 16, 0, 0);
 }
 
+// the same with an immediate offset, which the instruction adds to BOTH the global and the LDS address
+template <int OFF>
+__device__ __forceinline__ void fdma16_off(const void *src, void *lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_dst, 16, OFF, 0);
+}
+
 constexpr int SW_PLANE = 128 * FKT;  // 8 KB: 128 rows of one digit plane per stage
 constexpr int SW_MAX_M = 16000;
 
@@ -1089,31 +1095,38 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     const int8_t *xsrc[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) xsrc[u] = xplanes + (size_t)i_dr[u] * dpad + dc[u] * 16;
+    xsrc[1] -= 1024;  // its DMA carries the immediate offset 1024 (for the LDS side)
     const int nkt = dpad / FKT;  // >= 2 (filter_dpad)
     const int nchunk = (M + BJ - 1) / BJ;
     const int ntile = nkt * nchunk;
     const int c0 = jlo / BJ;
 
     int i_kt = 0, i_chunk = c0, i_stage = 0;
-    const uint32_t lane16 = 16u * lane;
-    // the 6 LDS-DMA instructions of a tile: X rows 16 (2 w + u) .. (ops 0, 1), W rows
-    // 16 (w + 4 v) .. of the chunk (ops 2 + v); ops [lo, hi) are issued, hi == DMA_TILE advances
+    // The 6 LDS-DMA instructions of a tile: X rows 16 (2 w + u) .. (ops 0, 1), then the wave's four
+    // consecutive KiB of the chunk's W rows (ops 2 + v: rows 16 (4 w + v) ..) -- ONE address and one
+    // LDS base for the four, the KiB steps sit in the instruction's immediate offset (it moves the
+    // global and the LDS address alike).  Ops [lo, hi) are issued, hi == DMA_TILE advances.
+    const int8_t *wlane = wplanes + 16u * lane + 4096u * wave;  // this lane's 16 bytes of the wave's 4 KiB
+    const size_t w_tile_step = (size_t)w_rows * FKT;
+    size_t i_woff = (size_t)c0 * BJ * FKT;  // (i_kt w_rows + i_chunk BJ) FKT, kept incrementally
     auto issue_ops = [&](int lo, int hi) {
         char *stage = smem + i_stage;
         const int k0 = i_kt * FKT;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (u >= lo && u < hi) fdma16(xsrc[u] + k0, stage + 1024 * (2 * wave + u));
-        const int8_t *wsrc = wplanes + ((size_t)i_kt * w_rows + (size_t)i_chunk * BJ) * FKT + lane16;
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-            if (2 + v >= lo && 2 + v < hi)
-                fdma16(wsrc + 1024 * (wave + 4 * v), stage + L::X_BYTES + 1024 * (wave + 4 * v));
+        if (0 >= lo && 0 < hi) fdma16(xsrc[0] + k0, stage + 2048 * wave);
+        if (1 >= lo && 1 < hi) fdma16_off<1024>(xsrc[1] + k0, stage + 2048 * wave);
+        const int8_t *wsrc = wlane + i_woff;
+        char *wdst = stage + L::X_BYTES + 4096 * wave;
+        if (2 >= lo && 2 < hi) fdma16(wsrc, wdst);
+        if (3 >= lo && 3 < hi) fdma16_off<1024>(wsrc, wdst);
+        if (4 >= lo && 4 < hi) fdma16_off<2048>(wsrc, wdst);
+        if (5 >= lo && 5 < hi) fdma16_off<3072>(wsrc, wdst);
         if (hi == DMA_TILE) {
             i_stage = (i_stage == (FSTAGES - 1) * L::STAGE) ? 0 : i_stage + L::STAGE;
+            i_woff += w_tile_step;
             if (++i_kt == nkt) {
                 i_kt = 0;
                 i_chunk = (i_chunk + 1 == nchunk) ? 0 : i_chunk + 1;
+                i_woff = (size_t)i_chunk * BJ * FKT;
             }
         }
     };
