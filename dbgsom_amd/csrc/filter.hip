@@ -539,7 +539,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     // the DMA_TILE = NPL (1 + JT) LDS-DMA instructions of a tile: X plane p (op p), then W rows
     // 128 u .. of plane p (op NPL + u NPL + p); ops [lo, hi) are issued, hi == DMA_TILE also
     // sends the chunk tables (first k-tile of a chunk) and advances the issue counters
-    const uint32_t lane_off = 1024u * wave + 16u * lane;  // this lane's 16 bytes of a wave's contiguous KiB
+    const uint32_t lane_off = 1024u * JT * wave + 16u * lane;  // this lane's 16 bytes of the wave's JT contiguous KiB
     auto issue_ops = [&](int lo, int hi) {
         char *stage = smem + i_stage;
         const int i_tile = tile_of(i_kt);
@@ -551,15 +551,22 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
             if (p >= lo && p < hi) fdma16(xsrc + p * xps + k0, stage + p * SW_PLANE + 1024 * wave);
+        // k-tile-major planes: 16 rows of a k-tile are one contiguous KiB; wave w takes the JT
+        // consecutive KiB 16 (JT w + u) .. of the chunk -- one address and one LDS base per plane,
+        // the KiB steps in the instruction's immediate offset (global and LDS side alike)
+        const int8_t *wsrc = wplanes + ((size_t)i_tile * w_rows + jc_t) * FKT + lane_off;
 #pragma unroll
         for (int u = 0; u < JT; ++u) {
-            // k-tile-major planes: rows 16 w .. 16 w + 15 of this k-tile are one contiguous KiB
-            const int8_t *wsrc = wplanes + ((size_t)i_tile * w_rows + jc_t + 128 * u) * FKT + lane_off;
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
-                if (NPL + u * NPL + p >= lo && NPL + u * NPL + p < hi)
-                    fdma16(wsrc + p * wps,
-                           stage + NPL * SW_PLANE + p * L::W_PLANE + 8192 * u + 1024 * wave);
+                if (NPL + u * NPL + p >= lo && NPL + u * NPL + p < hi) {
+                    const int8_t *src = wsrc + p * wps;
+                    char *dst = stage + NPL * SW_PLANE + p * L::W_PLANE + 1024 * JT * wave;
+                    if (u == 0) fdma16(src, dst);
+                    else if (u == 1) fdma16_off<1024>(src, dst);
+                    else if (u == 2) fdma16_off<2048>(src, dst);
+                    else fdma16_off<3072>(src, dst);
+                }
         }
         if (hi == DMA_TILE) {
             if (i_kt == 0) {  // this chunk's tables (1 KB pieces; the 8 waves cover them, twice for JT = 1)
@@ -1822,17 +1829,18 @@ size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M) {
     return carve_filter(nullptr, nullptr, N, d, M);
 }
 
-/* wavefronts per workgroup of the one-product candidate sweep for this map: 4 (128 x 256 tile, two
- * workgroups per CU) or 8 (128 x 512 tile, one per CU); see the cost model at the launch */
+/* wavefronts per workgroup of the one-product candidate sweep for this map: 4 (sweep4_i8_kernel,
+ * 128 x 256 tile, two workgroups per CU) or 8 (sweep_i8_kernel<0,1,JT>, one per CU).  Measured on
+ * the four BASELINE shapes (ms per launch, 8 / 4 wavefronts): C4 1.37 / 1.11, C3 1.12 / 0.88,
+ * C5 shard 4.99 / 4.83, C2 0.059 / 0.058 -- the small shape everywhere, although it reads the X
+ * plane once per 256 prototypes instead of once per 512 (C5: 16.4 GB per launch, 3.4 TB/s). */
 int dbgsom_sweep_shape(int64_t M, int64_t d) {
     static const int forced = [] {  // DBGSOM_SWEEP_SHAPE=4 / 8 forces one
         const char *e = getenv("DBGSOM_SWEEP_SHAPE");
         return e ? atoi(e) : 0;
     }();
-    if (forced == 4 || forced == 8) return forced;
-    if (M < 1 || d < 1) return 8;
-    const double nkt = (double)(filter_dpad(d) / FKT), c4 = (double)((M + 255) / 256), c8 = (double)((M + 511) / 512);
-    return (c4 * nkt * 1766.0 < nkt * c8 * 2300.0 + 37000.0) ? 4 : 8;
+    (void)M; (void)d;
+    return forced == 8 ? 8 : 4;
 }
 
 int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
@@ -1928,12 +1936,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                        xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab, f.yypad,    \
                        f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad,     \
                        f.ucount, (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr)
-    // One digit product: 8-wavefront workgroups (128 x 512 tile, one per CU) or 4-wavefront ones
-    // (128 x 256 tile, two per CU).  The small shape overlaps what the big one serialises (its tile
-    // loop runs ~10-17 % faster per unit of work and the per-workgroup overhead hides), but it reads
-    // the X plane once per 256 prototypes instead of once per 512 and that gather stream tops out
-    // near 2.9 TB/s.  Cost model from the measured C2-C5 launches, in cycles per workgroup:
-    // big shape nkt * chunks * 2300 + 37000; small shape bound by bytes = chunks * nkt * 1766.
+    // one digit product: 4-wavefront workgroups unless DBGSOM_SWEEP_SHAPE=8 (see dbgsom_sweep_shape)
     const int sweep_shape = dbgsom_sweep_shape(M, d);
     if (sweep_planes == 1 && sweep_shape == 4 && order_dev) {
         // one digit product, 4-wavefront workgroups (128 x 256 tile), two of them per CU

@@ -147,7 +147,8 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
 int dbgsom_filter_timing(int enable);
 int dbgsom_bmu_filtered_stage_ms(double *ms5);
 /* diagnostics: which shape of the one-product candidate sweep a map of M prototypes x d features
- * gets: 4 = sweep4_i8_kernel (4-wavefront workgroups, two per CU), 8 = sweep_i8_kernel<0,1,JT> */
+ * gets: 4 = sweep4_i8_kernel (4-wavefront workgroups, two per CU; the default), 8 =
+ * sweep_i8_kernel<0,1,JT> (environment DBGSOM_SWEEP_SHAPE=8) */
 int dbgsom_sweep_shape(int64_t M, int64_t d);
 /* diagnostics: candidate-list length of every 128-sample workgroup of the last filtered call */
 int dbgsom_bmu_filtered_counts(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
