@@ -987,6 +987,7 @@ struct Sweep4Lds {
 };
 static_assert(Sweep4Lds::BYTES <= 81920, "two workgroups per CU");
 
+template <int MODE>
 __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx,
     const double *__restrict__ l1x, const double *__restrict__ xx, int64_t N, int d, int dpad,
@@ -994,7 +995,8 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     const double *__restrict__ ctab_g, const double *__restrict__ yraw,
     const double *__restrict__ craw, const double *__restrict__ summary, int M,
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
-    uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, int w_rows) {
+    uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, int w_rows,
+    int64_t *__restrict__ seed, int jstride, int nkt_used, const int32_t *__restrict__ kt_sel) {
     using L = Sweep4Lds;
     constexpr int JT = L::JT, BJ = L::BJ, PLANES = 1;
     constexpr int DMA_TILE = 6;  // per wave and tile: 2 KiB of X rows, 4 KiB of W rows
@@ -1014,7 +1016,7 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     const int64_t p0 = (int64_t)blockIdx.x * 128;
     const int nwords = (M + 31) / 32;
 
-    auto sample_at = [&](int64_t p) -> int64_t { return (int64_t)order[p]; };
+    auto sample_at = [&](int64_t p) -> int64_t { return (MODE == 0) ? (int64_t)order[p] : p; };
     // every thread's own loads first (see sweep_i8_kernel)
     int64_t i_dr[2];
     int dc[2];
@@ -1035,9 +1037,11 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         s_i[it] = sx[i_il[it]];
-        l1_i[it] = l1x[i_il[it]];
-        xx_i[it] = xx[i_il[it]];
+        l1_i[it] = MODE == 0 ? l1x[i_il[it]] : 0.0;
+        xx_i[it] = MODE == 0 ? xx[i_il[it]] : 0.0;
     }
+    int jlo = 0, jhi = -1;
+    if constexpr (MODE == 0) {
     for (int w = tid; w < nwords; w += S4_NT) mask[w] = 0u;
     if (tid < 128) {
         const int64_t p = p0 + tid;
@@ -1061,8 +1065,8 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
         }
     }
     __syncthreads();
-    const int jlo = __builtin_amdgcn_readfirstlane(misc[0]);
-    const int jhi = __builtin_amdgcn_readfirstlane(misc[1]);
+    jlo = __builtin_amdgcn_readfirstlane(misc[0]);
+    jhi = __builtin_amdgcn_readfirstlane(misc[1]);
     if (jlo / BJ != jhi / BJ) {  // seeds in a later chunk: their bound up front (2 threads per sample)
         const int il = tid >> 1, q = tid & 1;
         const int64_t p = p0 + il;
@@ -1090,20 +1094,28 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
         }
         __syncthreads();
     }
+    }  // MODE == 0
 
-    double eps2_i[2], A_i[2];
-    const double l1w_max = summary[0], t_max = summary[1], yy_max = summary[2];
+    double eps2_i[2] = {0.0, 0.0}, A_i[2] = {0.0, 0.0};
+    if constexpr (MODE == 0) {
+        const double l1w_max = summary[0], t_max = summary[1], yy_max = summary[2];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        eps2_i[it] = 2.0 * filter_eps(s_i[it], l1_i[it], xx_i[it], l1w_max, t_max, yy_max, d, PLANES);
-        A_i[it] = thr_s[wi * 64 + it * 32 + lc];
+        for (int it = 0; it < 2; ++it) {
+            eps2_i[it] = 2.0 * filter_eps(s_i[it], l1_i[it], xx_i[it], l1w_max, t_max, yy_max, d, PLANES);
+            A_i[it] = thr_s[wi * 64 + it * 32 + lc];
+        }
     }
+    double bestv[2] = {INFINITY, INFINITY};  // MODE 1: running arg-min of r~
+    int bestj[2] = {0, 0};
 
     const int8_t *xsrc[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) xsrc[u] = xplanes + (size_t)i_dr[u] * dpad + dc[u] * 16;
     xsrc[1] -= 1024;  // its DMA carries the immediate offset 1024 (for the LDS side)
-    const int nkt = dpad / FKT;  // >= 2 (filter_dpad)
+    // MODE 1 may look at a sample of the k-tiles only (kt_sel, see dbgsom_bmu_filtered)
+    const int nkt_full = dpad / FKT;  // >= 2 (filter_dpad)
+    const int nkt = (MODE == 1 && nkt_used >= 2 && nkt_used < nkt_full) ? nkt_used : nkt_full;
+    auto tile_of = [&](int kt) { return (MODE == 1 && nkt < nkt_full) ? (int)kt_sel[kt] : kt; };
     const int nchunk = (M + BJ - 1) / BJ;
     const int ntile = nkt * nchunk;
     const int c0 = jlo / BJ;
@@ -1118,7 +1130,9 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     size_t i_woff = (size_t)c0 * BJ * FKT;  // (i_kt w_rows + i_chunk BJ) FKT, kept incrementally
     auto issue_ops = [&](int lo, int hi) {
         char *stage = smem + i_stage;
-        const int k0 = i_kt * FKT;
+        const int i_tile = tile_of(i_kt);
+        const int k0 = i_tile * FKT;
+        if constexpr (MODE == 1) i_woff = ((size_t)i_tile * w_rows + (size_t)i_chunk * BJ) * FKT;
         if (0 >= lo && 0 < hi) fdma16(xsrc[0] + k0, stage + 2048 * wave);
         if (1 >= lo && 1 < hi) fdma16_off<1024>(xsrc[1] + k0, stage + 2048 * wave);
         const int8_t *wsrc = wlane + i_woff;
@@ -1252,7 +1266,7 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int jc = r_chunk * BJ;
-            const bool has_prev = (jc <= jhi) && (jc + BJ - 1 >= jlo);
+            const bool has_prev = MODE == 0 && (jc <= jhi) && (jc + BJ - 1 >= jlo);
             int jl0 = wj * 32 * JT + 4 * lh;
             asm volatile("" : "+v"(jl0));
             if (has_prev) {
@@ -1294,17 +1308,27 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
                         uint64_t pass = 0;
 #pragma unroll
                         for (int it = 0; it < 2; ++it) {
-                            const double Tp = (double)acc[jt][it][r];
-                            pass |= __builtin_amdgcn_ballot_w64((A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp);
+                            if constexpr (MODE == 0) {
+                                const double Tp = (double)acc[jt][it][r];
+                                pass |= __builtin_amdgcn_ballot_w64((A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp);
+                            } else {  // tables in plain form here: r~ - |x_i|^2 = |w|^2 - s c T
+                                const int j = jc + jl0 + jt * 32 + 8 * g + i;
+                                const double rv = y4[i] - s_i[it] * (c4[i] * sweep_T<PLANES>(acc[jt][it][r], 0, 0));
+                                if (j < M && rv < bestv[it]) { bestv[it] = rv; bestj[it] = j * jstride; }
+                            }
                         }
-                        word |= (uint32_t)((uint32_t)pass != 0u) << (8 * g + i);
-                        word |= (uint32_t)((uint32_t)(pass >> 32) != 0u) << (4 + 8 * g + i);
+                        if constexpr (MODE == 0) {
+                            word |= (uint32_t)((uint32_t)pass != 0u) << (8 * g + i);
+                            word |= (uint32_t)((uint32_t)(pass >> 32) != 0u) << (4 + 8 * g + i);
+                        }
                     }
                 }
-                const int wbase = jc + wj * 32 * JT + jt * 32;
-                if (wbase < M) {
-                    if (M - wbase < 32) word &= (1u << (M - wbase)) - 1u;
-                    if (word != 0u && lane == 0) atomicOr(&mask[wbase >> 5], word);
+                if constexpr (MODE == 0) {
+                    const int wbase = jc + wj * 32 * JT + jt * 32;
+                    if (wbase < M) {
+                        if (M - wbase < 32) word &= (1u << (M - wbase)) - 1u;
+                        if (word != 0u && lane == 0) atomicOr(&mask[wbase >> 5], word);
+                    }
                 }
             }
 #pragma unroll
@@ -1322,6 +1346,32 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
         r_stage = r_next;
     }
 
+    if constexpr (MODE == 1) {
+        // seed = arg-min of r~ over the 2 lane halves and the 2 prototype wavefronts
+        __syncthreads();
+        double *sv = reinterpret_cast<double *>(smem);          // [2][128]
+        int *sj = reinterpret_cast<int *>(smem + 2 * 128 * 8);  // [2][128]
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const double ov = __shfl_xor(bestv[it], 32, 64);
+            const int oj = __shfl_xor(bestj[it], 32, 64);
+            if (ov < bestv[it] || (ov == bestv[it] && oj < bestj[it])) { bestv[it] = ov; bestj[it] = oj; }
+            if (lh == 0) {
+                sv[wj * 128 + wi * 64 + it * 32 + lc] = bestv[it];
+                sj[wj * 128 + wi * 64 + it * 32 + lc] = bestj[it];
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && p0 + tid < N) {
+            double bv = sv[tid];
+            int bj = sj[tid];
+            const double ov = sv[128 + tid];
+            const int oj = sj[128 + tid];
+            if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+            seed[p0 + tid] = (int64_t)bj;
+        }
+        return;
+    }
     __syncthreads();
     if (wave == 0) {  // compact the marked prototypes, ascending
         uint32_t base = 0;
@@ -1912,7 +1962,16 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         // the pre-pass is as coarse as the sweep it seeds: one product for the one-product sweep
         // (seeds need not be good, only cheap), three otherwise (data on which the coarse bound
         // fails also gets useless seeds from a one-product pre-pass)
-        if (sweep_planes == 1)
+        static const int prepass_shape = [] {  // DBGSOM_PREPASS_SHAPE=8: the 8-wavefront pre-pass
+            const char *e = getenv("DBGSOM_PREPASS_SHAPE");
+            return e ? atoi(e) : 4;
+        }();
+        if (sweep_planes == 1 && prepass_shape == 4)
+            hipLaunchKernelGGL(sweep4_i8_kernel<1>, dim3((unsigned)f.nb), dim3(S4_NT), 0, s, xb.planes, xb.scale,
+                               xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub, f.yy_sub,
+                               f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
+                               f.ulist, (int)f.Mpad, f.ucount, Msubpad, f.seed, seed_stride, nkt_used, f.kt_sel);
+        else if (sweep_planes == 1)
             hipLaunchKernelGGL((sweep_i8_kernel<1, 1, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub,
                            f.yy_sub, f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
@@ -1940,10 +1999,10 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     const int sweep_shape = dbgsom_sweep_shape(M, d);
     if (sweep_planes == 1 && sweep_shape == 4 && order_dev) {
         // one digit product, 4-wavefront workgroups (128 x 256 tile), two of them per CU
-        hipLaunchKernelGGL(sweep4_i8_kernel, dim3((unsigned)f.nb), dim3(S4_NT), 0, s, xb.planes, xb.scale,
+        hipLaunchKernelGGL(sweep4_i8_kernel<0>, dim3((unsigned)f.nb), dim3(S4_NT), 0, s, xb.planes, xb.scale,
                            xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab, f.yypad, f.ctab,
                            f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int)f.Mpad);
+                           (int)f.Mpad, (int64_t *)nullptr, 1, 0, (const int32_t *)nullptr);
     } else if (sweep_planes == 1) {  // one digit product: 128 x 512 tile (128 x 256 for small maps)
         if (M > 256) DBGSOM_SWEEP(1, 4); else DBGSOM_SWEEP(1, 2);
     } else if (sweep_planes == 3)
