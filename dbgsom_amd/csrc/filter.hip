@@ -874,7 +874,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                     for (int lv = 0; lv < NLV; ++lv)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[jt][it][lv][r] = 0;
-            r_kt = 0;
             r_chunk = (r_chunk + 1 == nchunk) ? 0 : r_chunk + 1;
             r_cseq = (r_cseq == 2) ? 0 : r_cseq + 1;
             load_frags(r_next, 0, f0);
@@ -882,9 +881,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 #if SWEEP_EXPERIMENT & 256
             ++e_seq;
 #endif
-        } else {
-            ++r_kt;
         }
+        r_kt = (r_kt == nkt - 1) ? 0 : r_kt + 1;  // a select: see sweep4_i8_kernel
         r_stage = r_next;
     }
 
@@ -1337,12 +1335,13 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
                 for (int it = 0; it < 2; ++it)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[jt][it][r] = 0;
-            r_kt = 0;
             r_chunk = (r_chunk + 1 == nchunk) ? 0 : r_chunk + 1;
             load_frags(r_next, 0, f0);
-        } else {
-            ++r_kt;
         }
+        // (a select, not an assignment per branch: the merge of the two paths otherwise gets an
+        // undefined scalar that the compiler fills from an accumulator register -- a wait for the
+        // last MFMA of every tile)
+        r_kt = (r_kt == nkt - 1) ? 0 : r_kt + 1;
         r_stage = r_next;
     }
 
