@@ -668,3 +668,20 @@ def test_adaptive_digit_planes_settle_on_the_cheaper_sweep(o):
         assert used[-1] == best, (used, means)
         if settle is None:
             assert used[-1] >= 2, (used, means)
+
+
+def test_eight_wavefront_sweep_and_prepass_still_agree_with_the_all_pairs_kernel():
+    """The 4-wavefront kernels are the default shape of the one-product sweep and of the seed
+    pre-pass; the 8-wavefront ones (DBGSOM_SWEEP_SHAPE=8 / DBGSOM_PREPASS_SHAPE=8, read once per
+    process) are checked in a child process by the randomised comparison against the all-pairs
+    kernel."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DBGSOM_SWEEP_SHAPE="8", DBGSOM_PREPASS_SHAPE="8")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_filtered.py"), "7", "24"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "24 cases, 0 mismatches" in out.stdout, out.stdout[-2000:]
