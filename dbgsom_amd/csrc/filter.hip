@@ -43,7 +43,8 @@ constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
 #endif
 #ifndef SWEEP_EXPERIMENT
 #define SWEEP_EXPERIMENT 0  // 4 no MFMA, 8 no chunk epilogue,
-// 64 (with 8) products dead, 256 in-kernel s_memtime stamps (tools/sweep_stamps.py)
+// 64 (with 8) products dead, 256 in-kernel s_memtime stamps (tools/sweep_stamps.py), 512 passing
+// pairs (tools/sweep_survivors.py), 1024 stamps in sweep4_i8_kernel (tools/sweep4_stamps.py)
 #endif
 
 // plane rows are padded to whole k-tiles, at least two of them (the sweep's ring runs three tiles
@@ -972,6 +973,9 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
 // belong to different workgroups -- they are not tied to the same barrier, and one workgroup's
 // prologue, chunk epilogues and list compaction run under the other's products.
 constexpr int S4_NT = 256;
+#ifndef S4_SPLIT_ISSUE
+#define S4_SPLIT_ISSUE 0  // 1: half of a tile's DMAs behind the barrier, half in the next tile's first half
+#endif
 struct Sweep4Lds {
     static constexpr int JT = 4, BJ = 256;
     static constexpr int X_BYTES = 128 * FKT, W_BYTES = BJ * FKT, STAGE = X_BYTES + W_BYTES;  // 8 + 16 KB
@@ -1220,28 +1224,40 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     asm volatile("" ::: "memory");
     Frags f0, f1;
     load_frags(0, 0, f0);
+#if SWEEP_EXPERIMENT & 1024
+    // (inside the unused tail of the mask area -- M <= 8192 -- so that two workgroups still fit a CU)
+    unsigned *s4stamps = reinterpret_cast<unsigned *>(smem + L::OFF_MASK + 1024);
+    const bool stamper = lane == 0;
+#define S4STAMP(k) if (stamper && t >= 16 && t < 26) s4stamps[wave * 60 + (t - 16) * 6 + (k)] = (unsigned)__builtin_amdgcn_s_memtime()
+#else
+#define S4STAMP(k)
+#endif
     int r_kt = 0, r_chunk = c0, r_stage = 0;
     bool tab_pending = false;  // a table DMA was issued in the previous tile's second half
     for (int t = 0; t < ntile; ++t) {
         const int r_next = (r_stage == (FSTAGES - 1) * L::STAGE) ? 0 : r_stage + L::STAGE;
         const bool back_now = t >= 1 && t + 2 < ntile;
+        S4STAMP(0);
         products(f0, [&](int g) {
             if (g == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_frags(r_stage, 1, f1);
                 touch_frags(f0);
-                if (back_now) issue_ops(DMA_TILE / 2, DMA_TILE);
+                if (S4_SPLIT_ISSUE && back_now) issue_ops(DMA_TILE / 2, DMA_TILE);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
         __builtin_amdgcn_sched_barrier(0);
         // own DMAs of tile t + 1 landed: what may stay in flight is tile t + 2 (and the table piece
         // issued behind the previous barrier, which sits between tiles t + 2 and t + 3 in the queue)
+        S4STAMP(1);
         if (t + 2 < ntile) wait_vm(DMA_TILE + (tab_pending ? 1 : 0));
         else wait_vm(0);
+        S4STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        S4STAMP(3);
         tab_pending = false;
         const bool front_now = t + 3 < ntile;
         products(f1, [&](int g) {
@@ -1252,15 +1268,17 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
                 // every wave is past the previous chunk's epilogue here: the table set may be
                 // replaced by this chunk's
                 if (r_kt == 0 && t > 0) { issue_tables(r_chunk); tab_pending = true; }
-                if (front_now) issue_ops(0, DMA_TILE / 2);
+                if (front_now) issue_ops(0, S4_SPLIT_ISSUE ? DMA_TILE / 2 : DMA_TILE);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
 
+        S4STAMP(4);
         if (r_kt == nkt - 1) {
             // the table pieces of this chunk: own piece landed (at most the 9 DMAs issued behind it
             // are in flight), then everybody's
-            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            if (S4_SPLIT_ISSUE) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int jc = r_chunk * BJ;
@@ -1393,6 +1411,12 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
             base += __shfl(pre, 63, 64);
         }
         if (lane == 0) ucount[blockIdx.x] = base;
+#if SWEEP_EXPERIMENT & 1024
+        {   // stamps of the four waves behind the list: uint32 at uint16 offset 512 of this row
+            unsigned *dbg = reinterpret_cast<unsigned *>(out + 512);
+            for (int e = lane; e < 240; e += 64) dbg[e] = s4stamps[e] - s4stamps[0];
+        }
+#endif
     }
 }
 
@@ -2054,7 +2078,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     return launch_status("filtered bmu kernels");
 }
 
-#if SWEEP_EXPERIMENT & (256 | 512)
+#if SWEEP_EXPERIMENT & (256 | 512 | 1024)
 size_t dbgsom_debug_ulist_offset(int64_t N, int64_t d, int64_t M) {
     FilterWs f;
     carve_filter(&f, (char *)nullptr, N, d, M);
