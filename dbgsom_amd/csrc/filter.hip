@@ -965,13 +965,14 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     }
 }
 
-// ---- 2a'. the one-product candidate sweep as 4-wavefront workgroups ---------------------------
+// ---- 2a'. the one-product candidate sweep, two workgroups per CU -------------------------------
 // Same arithmetic, bound, marking rule and outputs as sweep_i8_kernel<0, 1, JT>; another shape of
-// the same work: 256 threads = 4 wavefronts as 2 (samples) x 2 (prototypes), workgroup tile 128
-// samples x 256 prototypes, wavefront tile 64 x 128.  The ring stages are 24 KB and ONE set of chunk
-// tables is kept, 79.5 KB of LDS in all: TWO workgroups share a CU, so the two wavefronts of a SIMD
-// belong to different workgroups -- they are not tied to the same barrier, and one workgroup's
-// prologue, chunk epilogues and list compaction run under the other's products.
+// the same work: workgroup tile 128 samples x 256 prototypes, 24 KB ring stages and ONE set of chunk
+// tables, 79.5 KB of LDS in all, so that TWO workgroups share a CU: the wavefronts of a SIMD belong
+// to different workgroups -- they are not tied to the same barrier, and one workgroup's prologue,
+// chunk epilogues and list compaction run under the other's products.  NW = 4 wavefronts as 2 x 2
+// (wavefront tile 64 x 128, two wavefronts per SIMD) or NW = 8 as 2 x 4 (64 x 64 tiles, 64
+// accumulator registers, <= 128 VGPRs: FOUR wavefronts per SIMD -- the default).
 constexpr int S4_NT = 256;
 #ifndef S4_SPLIT_ISSUE
 #define S4_SPLIT_ISSUE 0  // 1: half of a tile's DMAs behind the barrier, half in the next tile's first half
@@ -983,14 +984,16 @@ struct Sweep4Lds {
     static constexpr int OFF_TAB = FSTAGES * STAGE;
     static constexpr int OFF_THR = OFF_TAB + 2 * TAB;
     static constexpr int OFF_PREV = OFF_THR + 128 * 8;
-    static constexpr int OFF_MASK = OFF_PREV + 128 * 4;
-    static constexpr int OFF_MISC = OFF_MASK + (SW_MAX_M + 31) / 32 * 4;
+    static constexpr int OFF_EPS = OFF_PREV + 128 * 4;   // 2 eps_i per sample (MODE 0)
+    static constexpr int OFF_MASK = OFF_EPS + 128 * 8;
+    static constexpr int MAX_M = 8192;                   // bitmask of the marked prototypes: 1 KB
+    static constexpr int OFF_MISC = OFF_MASK + MAX_M / 8;
     static constexpr int BYTES = OFF_MISC + 16;
 };
 static_assert(Sweep4Lds::BYTES <= 81920, "two workgroups per CU");
 
-template <int MODE>
-__global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: the second figure is waves per SIMD)
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx,
     const double *__restrict__ l1x, const double *__restrict__ xx, int64_t N, int d, int dpad,
     const int8_t *__restrict__ wplanes, const double *__restrict__ ytab_g,
@@ -1000,8 +1003,12 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, int w_rows,
     int64_t *__restrict__ seed, int jstride, int nkt_used, const int32_t *__restrict__ kt_sel) {
     using L = Sweep4Lds;
-    constexpr int JT = L::JT, BJ = L::BJ, PLANES = 1;
-    constexpr int DMA_TILE = 6;  // per wave and tile: 2 KiB of X rows, 4 KiB of W rows
+    // NW wavefronts as 2 (samples) x WJ (prototypes), wavefront tile 64 x 32 JT: 4 -> 64 x 128,
+    // 8 -> 64 x 64 (64 accumulator registers: <= 128 VGPRs, four wavefronts per SIMD)
+    constexpr int NT = NW * 64, WJ = NW / 2, JT = 8 / WJ, BJ = L::BJ, PLANES = 1;
+    static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts");
+    constexpr int XI = 8 / NW, WI = 16 / NW;  // LDS-DMA instructions per wave and tile: X rows, W rows
+    constexpr int DMA_TILE = XI + WI;
     __shared__ __attribute__((aligned(16))) char smem[L::BYTES];
     double *thr_s = reinterpret_cast<double *>(smem + L::OFF_THR);
     int *prev_s = reinterpret_cast<int *>(smem + L::OFF_PREV);
@@ -1013,18 +1020,18 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = wave / WJ, wj = wave % WJ;
     const int lc = lane & 31, lh = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * 128;
     const int nwords = (M + 31) / 32;
 
     auto sample_at = [&](int64_t p) -> int64_t { return (MODE == 0) ? (int64_t)order[p] : p; };
     // every thread's own loads first (see sweep_i8_kernel)
-    int64_t i_dr[2];
-    int dc[2];
+    int64_t i_dr[XI];
+    int dc[XI];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {  // DMA: wave w loads X rows 32 w .. 32 w + 31, 16 per instruction
-        const int r = 16 * (2 * wave + u) + (lane >> 2);
+    for (int u = 0; u < XI; ++u) {  // DMA: wave w loads X rows 16 XI w .., 16 per instruction
+        const int r = 16 * (XI * wave + u) + (lane >> 2);
         const int64_t xpos = (p0 + r < N) ? (p0 + r) : (N - 1);
         i_dr[u] = sample_at(xpos);
         dc[u] = (lane & 3) ^ ((r >> 2) & 3);
@@ -1044,7 +1051,7 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     }
     int jlo = 0, jhi = -1;
     if constexpr (MODE == 0) {
-    for (int w = tid; w < nwords; w += S4_NT) mask[w] = 0u;
+    for (int w = tid; w < nwords; w += NT) mask[w] = 0u;
     if (tid < 128) {
         const int64_t p = p0 + tid;
         int pj = -1;
@@ -1069,8 +1076,9 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     __syncthreads();
     jlo = __builtin_amdgcn_readfirstlane(misc[0]);
     jhi = __builtin_amdgcn_readfirstlane(misc[1]);
-    if (jlo / BJ != jhi / BJ) {  // seeds in a later chunk: their bound up front (2 threads per sample)
-        const int il = tid >> 1, q = tid & 1;
+    if (jlo / BJ != jhi / BJ) {  // seeds in a later chunk: their bound up front (TPS threads per sample)
+        constexpr int TPS = NT / 128;
+        const int il = tid / TPS, q = tid % TPS;
         const int64_t p = p0 + il;
         const int pj = prev_s[il];
         const bool need = p < N && pj >= 0 && pj / BJ != jlo / BJ;
@@ -1079,7 +1087,7 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
         if (need) {
             const int8_t *xr = xplanes + (size_t)i * dpad;
             const int wsw = (pj >> 2) & 3;
-            for (int ch = q; ch < dpad / 16; ch += 2) {
+            for (int ch = q; ch < dpad / 16; ch += TPS) {
                 const int8_t *wr = wplanes + ((size_t)(ch >> 2) * w_rows + pj) * FKT + (((ch & 3) ^ wsw) << 4);
                 const v4i_t xv = *reinterpret_cast<const v4i_t *>(xr + ch * 16);
                 const v4i_t wv = *reinterpret_cast<const v4i_t *>(wr);
@@ -1087,7 +1095,8 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
                 for (int e = 0; e < 4; ++e) a0 = __builtin_amdgcn_sdot4(xv[e], wv[e], a0, false);
             }
         }
-        a0 += __shfl_xor(a0, 1, 64);
+#pragma unroll
+        for (int m = 1; m < TPS; m <<= 1) a0 += __shfl_xor(a0, m, 64);
         if (need && q == 0) {
             const double T = sweep_T<PLANES>(a0, 0, 0);
             const double sv = sx[i], xv2 = xx[i];
@@ -1098,22 +1107,25 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     }
     }  // MODE == 0
 
-    double eps2_i[2] = {0.0, 0.0}, A_i[2] = {0.0, 0.0};
+    // 2 eps_i and A_i = |x_i|^2 - thr_i live in LDS between the chunk epilogues (eight registers
+    // the 8-wavefront shape does not have)
+    double *eps_s = reinterpret_cast<double *>(smem + L::OFF_EPS);
     if constexpr (MODE == 0) {
         const double l1w_max = summary[0], t_max = summary[1], yy_max = summary[2];
+        if (wj == 0 && lh == 0) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            eps2_i[it] = 2.0 * filter_eps(s_i[it], l1_i[it], xx_i[it], l1w_max, t_max, yy_max, d, PLANES);
-            A_i[it] = thr_s[wi * 64 + it * 32 + lc];
+            for (int it = 0; it < 2; ++it)
+                eps_s[wi * 64 + it * 32 + lc] =
+                    2.0 * filter_eps(s_i[it], l1_i[it], xx_i[it], l1w_max, t_max, yy_max, d, PLANES);
         }
     }
     double bestv[2] = {INFINITY, INFINITY};  // MODE 1: running arg-min of r~
     int bestj[2] = {0, 0};
 
-    const int8_t *xsrc[2];
+    const int8_t *xsrc[XI];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) xsrc[u] = xplanes + (size_t)i_dr[u] * dpad + dc[u] * 16;
-    xsrc[1] -= 1024;  // its DMA carries the immediate offset 1024 (for the LDS side)
+    for (int u = 0; u < XI; ++u) xsrc[u] = xplanes + (size_t)i_dr[u] * dpad + dc[u] * 16;
+    if constexpr (XI == 2) xsrc[XI - 1] -= 1024;  // its DMA carries the immediate offset 1024 (for the LDS side)
     // MODE 1 may look at a sample of the k-tiles only (kt_sel, see dbgsom_bmu_filtered)
     const int nkt_full = dpad / FKT;  // >= 2 (filter_dpad)
     const int nkt = (MODE == 1 && nkt_used >= 2 && nkt_used < nkt_full) ? nkt_used : nkt_full;
@@ -1127,7 +1139,7 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     // consecutive KiB of the chunk's W rows (ops 2 + v: rows 16 (4 w + v) ..) -- ONE address and one
     // LDS base for the four, the KiB steps sit in the instruction's immediate offset (it moves the
     // global and the LDS address alike).  Ops [lo, hi) are issued, hi == DMA_TILE advances.
-    const int8_t *wlane = wplanes + 16u * lane + 4096u * wave;  // this lane's 16 bytes of the wave's 4 KiB
+    const int8_t *wlane = wplanes + 16u * lane + 1024u * WI * wave;  // this lane's 16 bytes of the wave's WI KiB
     const size_t w_tile_step = (size_t)w_rows * FKT;
     size_t i_woff = (size_t)c0 * BJ * FKT;  // (i_kt w_rows + i_chunk BJ) FKT, kept incrementally
     auto issue_ops = [&](int lo, int hi) {
@@ -1135,14 +1147,17 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
         const int i_tile = tile_of(i_kt);
         const int k0 = i_tile * FKT;
         if constexpr (MODE == 1) i_woff = ((size_t)i_tile * w_rows + (size_t)i_chunk * BJ) * FKT;
-        if (0 >= lo && 0 < hi) fdma16(xsrc[0] + k0, stage + 2048 * wave);
-        if (1 >= lo && 1 < hi) fdma16_off<1024>(xsrc[1] + k0, stage + 2048 * wave);
+        if (0 >= lo && 0 < hi) fdma16(xsrc[0] + k0, stage + 1024 * XI * wave);
+        if constexpr (XI == 2)
+            if (1 >= lo && 1 < hi) fdma16_off<1024>(xsrc[XI - 1] + k0, stage + 1024 * XI * wave);
         const int8_t *wsrc = wlane + i_woff;
-        char *wdst = stage + L::X_BYTES + 4096 * wave;
-        if (2 >= lo && 2 < hi) fdma16(wsrc, wdst);
-        if (3 >= lo && 3 < hi) fdma16_off<1024>(wsrc, wdst);
-        if (4 >= lo && 4 < hi) fdma16_off<2048>(wsrc, wdst);
-        if (5 >= lo && 5 < hi) fdma16_off<3072>(wsrc, wdst);
+        char *wdst = stage + L::X_BYTES + 1024 * WI * wave;
+        if (XI + 0 >= lo && XI + 0 < hi) fdma16(wsrc, wdst);
+        if (XI + 1 >= lo && XI + 1 < hi) fdma16_off<1024>(wsrc, wdst);
+        if constexpr (WI == 4) {
+            if (XI + 2 >= lo && XI + 2 < hi) fdma16_off<2048>(wsrc, wdst);
+            if (XI + 3 >= lo && XI + 3 < hi) fdma16_off<3072>(wsrc, wdst);
+        }
         if (hi == DMA_TILE) {
             i_stage = (i_stage == (FSTAGES - 1) * L::STAGE) ? 0 : i_stage + L::STAGE;
             i_woff += w_tile_step;
@@ -1153,8 +1168,10 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
             }
         }
     };
-    // the chunk tables (4 pieces of 1 KiB: |w|^2 / c halves, 1 / c halves), one piece per wave
+    // the chunk tables (4 pieces of 1 KiB: |w|^2 / c halves, 1 / c halves), one piece per wave 0 .. 3
+    const bool tab_wave = NW == 4 || wave < 4;
     auto issue_tables = [&](int chunk) {
+        if (!tab_wave) return;
         const int half = wave & 1;
         const int j2 = chunk * BJ + 128 * half + 2 * lane;  // tables are padded to whole 512-entry chunks
         char *tab = smem + L::OFF_TAB;
@@ -1200,7 +1217,7 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
 #pragma unroll
         for (int jh = 0; jh < JT; jh += 2) {
 #pragma unroll
-            for (int jt = jh; jt < jh + 2; ++jt)
+            for (int jt = jh; jt < jh + 2 && jt < JT; ++jt)
 #pragma unroll
                 for (int it = 0; it < 2; ++it)
                     acc[jt][it] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[jt], f.x[it], acc[jt][it], 0, 0, 0);
@@ -1225,9 +1242,9 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     Frags f0, f1;
     load_frags(0, 0, f0);
 #if SWEEP_EXPERIMENT & 1024
-    // (inside the unused tail of the mask area -- M <= 8192 -- so that two workgroups still fit a CU)
-    unsigned *s4stamps = reinterpret_cast<unsigned *>(smem + L::OFF_MASK + 1024);
-    const bool stamper = lane == 0;
+    // (inside the tail of the mask area -- M <= 512 in this build -- so that two workgroups still fit a CU)
+    unsigned *s4stamps = reinterpret_cast<unsigned *>(smem + L::OFF_MASK + 64);
+    const bool stamper = lane == 0 && wave < 4;
 #define S4STAMP(k) if (stamper && t >= 16 && t < 26) s4stamps[wave * 60 + (t - 16) * 6 + (k)] = (unsigned)__builtin_amdgcn_s_memtime()
 #else
 #define S4STAMP(k)
@@ -1267,7 +1284,7 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
                 touch_frags(f1);
                 // every wave is past the previous chunk's epilogue here: the table set may be
                 // replaced by this chunk's
-                if (r_kt == 0 && t > 0) { issue_tables(r_chunk); tab_pending = true; }
+                if (r_kt == 0 && t > 0) { issue_tables(r_chunk); tab_pending = tab_wave; }
                 if (front_now) issue_ops(0, S4_SPLIT_ISSUE ? DMA_TILE / 2 : DMA_TILE);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1277,8 +1294,8 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
         if (r_kt == nkt - 1) {
             // the table pieces of this chunk: own piece landed (at most the 9 DMAs issued behind it
             // are in flight), then everybody's
-            if (S4_SPLIT_ISSUE) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            // (the DMAs issued behind it: a tile and a half with split issue, two tiles without)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S4_SPLIT_ISSUE ? DMA_TILE + DMA_TILE / 2 : 2 * DMA_TILE) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int jc = r_chunk * BJ;
@@ -1298,12 +1315,17 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
                             const bool sel = jl == want;
                             a0s = sel ? acc[jt][it][r] : a0s;
                             jls = sel ? jl : jls;
+                            if constexpr (NW == 8) __builtin_amdgcn_sched_barrier(0);
                         }
                     if (jls >= 0)
                         thr_s[wi * 64 + it * 32 + lc] =
-                            (s_i[it] * (craw[jc + jls] * sweep_T<PLANES>(a0s, 0, 0)) - yraw[jc + jls]) - eps2_i[it];
+                            (s_i[it] * (craw[jc + jls] * sweep_T<PLANES>(a0s, 0, 0)) - yraw[jc + jls]) -
+                            eps_s[wi * 64 + it * 32 + lc];
                 }
                 __syncthreads();
+            }
+            double A_i[2] = {0.0, 0.0};
+            if constexpr (MODE == 0) {
 #pragma unroll
                 for (int it = 0; it < 2; ++it) A_i[it] = thr_s[wi * 64 + it * 32 + lc];
             }
@@ -1336,6 +1358,9 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
                         if constexpr (MODE == 0) {
                             word |= (uint32_t)((uint32_t)pass != 0u) << (8 * g + i);
                             word |= (uint32_t)((uint32_t)(pass >> 32) != 0u) << (4 + 8 * g + i);
+                            // (8 wavefronts: one compare pair at a time -- the scalar masks of many
+                            // hoisted compares spill, and spilled SGPRs cost VGPRs beyond the 128)
+                            if constexpr (NW == 8) __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
@@ -1366,8 +1391,8 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
     if constexpr (MODE == 1) {
         // seed = arg-min of r~ over the 2 lane halves and the 2 prototype wavefronts
         __syncthreads();
-        double *sv = reinterpret_cast<double *>(smem);          // [2][128]
-        int *sj = reinterpret_cast<int *>(smem + 2 * 128 * 8);  // [2][128]
+        double *sv = reinterpret_cast<double *>(smem);           // [WJ][128]
+        int *sj = reinterpret_cast<int *>(smem + WJ * 128 * 8);  // [WJ][128]
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const double ov = __shfl_xor(bestv[it], 32, 64);
@@ -1382,9 +1407,12 @@ __global__ __launch_bounds__(S4_NT, 2) void sweep4_i8_kernel(
         if (tid < 128 && p0 + tid < N) {
             double bv = sv[tid];
             int bj = sj[tid];
-            const double ov = sv[128 + tid];
-            const int oj = sj[128 + tid];
-            if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+#pragma unroll
+            for (int w = 1; w < WJ; ++w) {
+                const double ov = sv[w * 128 + tid];
+                const int oj = sj[w * 128 + tid];
+                if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+            }
             seed[p0 + tid] = (int64_t)bj;
         }
         return;
@@ -1922,6 +1950,20 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                         const int32_t *order_dev, int seed_stride, int sweep_planes,
                         int round_f32, int64_t *idx_dev, double *dist_dev, void *workspace_dev,
                         size_t workspace_bytes, void *stream) {
+    // 8 wavefronts of 64 x 64 tiles (<= 128 VGPRs: four wavefronts per SIMD, two workgroups per CU)
+    // or 4 of 64 x 128 (DBGSOM_SWEEP_WAVES=4; two wavefronts per SIMD).  Measured, ms per launch,
+    // 4 / 8: C4 1.13 / 1.04, C3 0.88 / 0.71, C5 shard 4.96 / 4.55
+    static const int s4_waves = [] {
+        const char *e = getenv("DBGSOM_SWEEP_WAVES");
+        return e ? atoi(e) : 8;
+    }();
+#define S4_LAUNCH(MODE_, NB, ...)                                                                   \
+    do {                                                                                           \
+        if (s4_waves == 8)                                                                         \
+            hipLaunchKernelGGL((sweep4_i8_kernel<MODE_, 8>), dim3((unsigned)(NB)), dim3(512), 0, s, __VA_ARGS__); \
+        else                                                                                       \
+            hipLaunchKernelGGL((sweep4_i8_kernel<MODE_, 4>), dim3((unsigned)(NB)), dim3(256), 0, s, __VA_ARGS__); \
+    } while (0)
     DBGSOM_REQUIRE(seed_stride >= 0 && seed_stride <= 64, "seed_stride outside [0, 64]");
     DBGSOM_REQUIRE(sweep_planes >= 0 && sweep_planes <= 3, "sweep_planes must be 0 .. 3");
     if (sweep_planes == 0) sweep_planes = 2;
@@ -1990,7 +2032,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
             return e ? atoi(e) : 4;
         }();
         if (sweep_planes == 1 && prepass_shape == 4)
-            hipLaunchKernelGGL(sweep4_i8_kernel<1>, dim3((unsigned)f.nb), dim3(S4_NT), 0, s, xb.planes, xb.scale,
+            S4_LAUNCH(1, f.nb, xb.planes, xb.scale,
                                xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub, f.yy_sub,
                                f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
                                f.ulist, (int)f.Mpad, f.ucount, Msubpad, f.seed, seed_stride, nkt_used, f.kt_sel);
@@ -2020,9 +2062,9 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                        f.ucount, (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr)
     // one digit product: 4-wavefront workgroups unless DBGSOM_SWEEP_SHAPE=8 (see dbgsom_sweep_shape)
     const int sweep_shape = dbgsom_sweep_shape(M, d);
-    if (sweep_planes == 1 && sweep_shape == 4 && order_dev) {
+    if (sweep_planes == 1 && sweep_shape == 4 && order_dev && M <= Sweep4Lds::MAX_M) {
         // one digit product, 4-wavefront workgroups (128 x 256 tile), two of them per CU
-        hipLaunchKernelGGL(sweep4_i8_kernel<0>, dim3((unsigned)f.nb), dim3(S4_NT), 0, s, xb.planes, xb.scale,
+        S4_LAUNCH(0, f.nb, xb.planes, xb.scale,
                            xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab, f.yypad, f.ctab,
                            f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
                            (int)f.Mpad, (int64_t *)nullptr, 1, 0, (const int32_t *)nullptr);
@@ -2069,6 +2111,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     DBGSOM_SUBSET(1, s2);
 #undef DBGSOM_SUBSET
 #undef DBGSOM_SWEEP
+#undef S4_LAUNCH
     if (fork) {
         DBGSOM_HIP_CHECK(hipEventRecord(side.joined, s2));
         DBGSOM_HIP_CHECK(hipStreamWaitEvent(s, side.joined, 0));
