@@ -49,7 +49,7 @@ I8_MFMA_PEAK_TOPS = 5033.0   # 256 x 4 x 2.4 GHz x 65536 op / 32 cycles (v_mfma_
 # (FETCH_SIZE x 2 per the gfx950 correction); not measurable inside this process.  Keyed by the
 # number of digit planes the sweep reads (1 -> sweep_i8_kernel<0,1,4>, 2 -> <0,2,2>, 3 -> <0,3,1>)
 SWEEP_TRAFFIC_C4_BYTES = {1: 1.99e9, 2: 7.90e9, 3: 2.42e10}
-SWEEP4_TRAFFIC_C4_BYTES = 4.18e9  # sweep4_i8_kernel (one product, 4-wavefront workgroups): plane 0 of X once per 256 prototypes
+SWEEP4_TRAFFIC_C4_BYTES = 4.14e9  # sweep4_i8_kernel (one product, 4-wavefront workgroups): plane 0 of X once per 256 prototypes
 SWEEP_KERNEL = {1: "sweep_i8_kernel<0,1,4>", 2: "sweep_i8_kernel<0,2,2>", 3: "sweep_i8_kernel<0,3,1>"}
 SWEEP_PRODUCTS = {1: 1, 2: 3, 3: 6}   # int8 digit products kept per (sample, prototype, k)
 
