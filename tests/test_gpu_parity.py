@@ -685,3 +685,29 @@ def test_eight_wavefront_sweep_and_prepass_still_agree_with_the_all_pairs_kernel
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "24 cases, 0 mismatches" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("N,d,M", [(3000, 32, 8192), (3000, 32, 9000), (100, 48, 200), (129, 16, 129),
+                                   (5000, 4096, 300)])
+def test_one_product_sweep_at_the_edges_of_its_shapes(N, d, M):
+    """The two-workgroups-per-CU sweep takes maps of up to 8192 prototypes (its bitmask is 1 KB of
+    LDS), larger ones fall back to the 8-wavefront kernel; fewer samples than one workgroup, a
+    single prototype chunk and very long rows (64 k-tiles) go through it too.  Winners, distances
+    and new prototypes are those of the all-pairs kernel, bit for bit."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(N + d + M)
+    X = (rng.normal(size=(N, d)) + 2.0 * rng.integers(0, 5, size=(N, 1))).astype(np.float32)
+    W = (X[rng.choice(N, M, replace=M > N)] + 1e-3 * rng.normal(size=(M, d))).astype(np.float64)
+    hop = np.zeros((M, M))
+    ex = HipBackend(algorithm="exact").load(X)
+    fi = HipBackend(algorithm="filtered").load(X)
+    fi.sweep_planes = 1
+    for _ in range(2):  # stateless, then with the first epoch's winners as seeds
+        re_ = ex.epoch(W, hop, 1.0, 1e-3, "compact", True)
+        rf = fi.epoch(W, hop, 1.0, 1e-3, "compact", True)
+        assert fi.filter_log[-1][0] == "filtered" and fi.filter_log[-1][2] == 1
+        assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances)
+        assert np.array_equal(rf.new_weights, re_.new_weights, equal_nan=True)
+        fi.algorithm = "filtered_hint"
+    ex.release(); fi.release()
