@@ -1502,13 +1502,13 @@ __global__ __launch_bounds__(256) void sched_fill_kernel(const uint32_t *__restr
 }
 
 // ---- 3. exact arg-min over the marked prototypes (float64 MFMA on gathered rows) -----------------
-// 128 gathered samples x SJ = 16 JTL listed prototypes per step; 4 wavefronts x 32 samples,
-// 3-stage LDS-DMA ring.  Three instantiations (JTL = 1, 2, 3) are launched back to back, each
+// 128 gathered samples x SJ = 16 JTL listed prototypes per step; 4 wavefronts x 32 samples or 8 x 16
+// (NWV), 3-stage LDS-DMA ring.  Three instantiations (JTL = 1, 2, 3) are launched back to back, each
 // takes the workgroups whose list length falls in its class (<= 16, 17..32, > 32) so that the
 // gathered X tile is streamed once for all but the longest lists (a fourth class of 64 was
 // measured: no gain at C3 / C4, slower at C2).
-template <typename XT, int JTL>
-__global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
+template <typename XT, int JTL, int NWV>
+__global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
     const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
     const double *__restrict__ W, int M, const double *__restrict__ ww,
     const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
@@ -1516,8 +1516,12 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     const uint32_t *__restrict__ sched_range, int round_f32, int64_t *__restrict__ idx_out,
     double *__restrict__ dist_out) {
     constexpr int SJ = 16 * JTL;
+    // NWV wavefronts x 16 IT samples: 4 x 32 (two sample tiles per wavefront) or 8 x 16 (one: half
+    // the accumulators, twice the wavefronts per SIMD)
+    static_assert(NWV == 4 || NWV == 8, "4 or 8 wavefronts");
+    constexpr int IT = 8 / NWV, WS = 16 * IT;
     // X tile: 128 rows x KT values, float32 (64-byte rows) or float64 (128-byte rows, laid out like W)
-    constexpr int XROW = KT * (int)sizeof(XT), XCH = XROW / 16, XD = 128 * XROW / 1024 / 4;
+    constexpr int XROW = KT * (int)sizeof(XT), XCH = XROW / 16, XD = 128 * XROW / 1024 / NWV;
     constexpr int S_XT = 128 * XROW, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 / 16 KB + 2 JTL KB
 #if SUBSET_EXPERIMENT & 64
     __shared__ __attribute__((aligned(16))) char smem[6 * S_STAGE];  // halves the blocks per CU
@@ -1545,17 +1549,17 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     const int64_t p0 = (int64_t)wg * 128;
     const uint16_t *list = ulist + (size_t)wg * ulist_stride;
 
-    double xi[2];
-    int64_t isamp[2];
+    double xi[IT];
+    int64_t isamp[IT];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int64_t p = p0 + wave * 32 + it * 16 + lr;
+    for (int it = 0; it < IT; ++it) {
+        const int64_t p = p0 + wave * WS + it * 16 + lr;
         isamp[it] = (p < N) ? order[p] : -1;
         xi[it] = (p < N) ? xx[isamp[it]] : 0.0;
     }
-    Best<1> best[2];
-    best[0].init();
-    best[1].init();
+    Best<1> best[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) best[it].init();
 
     // DMA sources. X tile: 8 (f32) / 16 (f64) instructions, wave w issues q = XD w .. XD w + XD - 1
     // = the rows of its own 32 samples
@@ -1572,8 +1576,11 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
     // W tile: SJ rows x 128 B = 2 JTL instructions (8 rows each), issued by waves 0 .. 2 JTL - 1
     // (JTL = 3: waves 0, 1 take two)
     constexpr int W_INSTR = 2 * JTL;
-    const int n_wdma = (wave < W_INSTR - 4) ? 2 : (wave < W_INSTR ? 1 : 0);  // 6 instr: 2,2,1,1
-    const int wq0 = (wave < W_INSTR - 4) ? 2 * wave : (W_INSTR > 4 ? wave + (W_INSTR - 4) : wave);
+    // 4 wavefronts, 6 instructions: 2, 2, 1, 1; 8 wavefronts: one each for waves 0 .. W_INSTR - 1
+    const int n_wdma = NWV == 8 ? (wave < W_INSTR ? 1 : 0)
+                                : ((wave < W_INSTR - 4) ? 2 : (wave < W_INSTR ? 1 : 0));
+    const int wq0 = NWV == 8 ? wave
+                             : ((wave < W_INSTR - 4) ? 2 * wave : (W_INSTR > 4 ? wave + (W_INSTR - 4) : wave));
     const int wlr = lane >> 3, wcp = lane & 7;
 
     const int nkt = d / KT;
@@ -1614,7 +1621,7 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         if (++i_kt == nkt) { i_kt = 0; ++i_step; }
     };
 
-    int a_off[JTL], a_swz[JTL], b_off[2], b_swz[2];
+    int a_off[JTL], a_swz[JTL], b_off[IT], b_swz[IT];
 #pragma unroll
     for (int u = 0; u < JTL; ++u) {
         const int ra = u * 16 + lr;
@@ -1622,8 +1629,8 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         a_swz[u] = (ra >> 1) & 7;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int rb = wave * 32 + u * 16 + lr;
+    for (int u = 0; u < IT; ++u) {
+        const int rb = wave * WS + u * 16 + lr;
         if constexpr (sizeof(XT) == 4) {
             b_off[u] = rb * XROW + lq * 4;
             b_swz[u] = (rb >> 1) & 3;
@@ -1633,11 +1640,11 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         }
     }
 
-    d4_t acc[JTL][2];
+    d4_t acc[JTL][IT];
 #pragma unroll
     for (int jt = 0; jt < JTL; ++jt)
 #pragma unroll
-        for (int it = 0; it < 2; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
+        for (int it = 0; it < IT; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
 
     if (ntile > 0) issue();
     if (ntile > 1) issue();
@@ -1672,11 +1679,12 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         r_stage = (r_stage == 2 * S_STAGE) ? 0 : r_stage + S_STAGE;
 #pragma unroll
         for (int ks = 0; ks < KT / 4; ++ks) {
-            double a[JTL], b[2];
+            double a[JTL], b[IT];
 #if SUBSET_EXPERIMENT & 8
 #pragma unroll
             for (int u = 0; u < JTL; ++u) a[u] = xi[0] + u;
-            b[0] = xi[1]; b[1] = xi[0];
+#pragma unroll
+            for (int u = 0; u < IT; ++u) b[u] = xi[u];
 #else
 #pragma unroll
             for (int u = 0; u < JTL; ++u) {
@@ -1684,7 +1692,7 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
                 a[u] = *reinterpret_cast<const double *>(stage + a_off[u] + ca * 16);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < IT; ++u) {
                 if constexpr (sizeof(XT) == 4) {
                     const int cb = ks ^ b_swz[u];
                     b[u] = (double)*reinterpret_cast<const float *>(stage + b_off[u] + cb * 16);
@@ -1697,7 +1705,7 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
 #pragma unroll
             for (int jt = 0; jt < JTL; ++jt)
 #pragma unroll
-                for (int it = 0; it < 2; ++it)
+                for (int it = 0; it < IT; ++it)
 #if SUBSET_EXPERIMENT & 4
                     acc[jt][it][0] += a[jt] * b[it];
 #else
@@ -1725,7 +1733,7 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
                     const int pos = st * SJ + jt * 16 + 4 * r + lq;
                     if (pos < cnt) {
 #pragma unroll
-                        for (int it = 0; it < 2; ++it) {
+                        for (int it = 0; it < IT; ++it) {
                             double rv = (xi[it] + (-2.0 * acc[jt][it][r])) + yv[r];
                             if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
                             best[it].push(rv, jv[r]);  // list ascends -> j ascends per lane
@@ -1736,7 +1744,7 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
 #pragma unroll
             for (int jt = 0; jt < JTL; ++jt)
 #pragma unroll
-                for (int it = 0; it < 2; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
+                for (int it = 0; it < IT; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
             kt = 0;
             ++st;
         } else {
@@ -1744,7 +1752,7 @@ __global__ __launch_bounds__(NT, 4) void subset_exact_kernel(
         }
     }
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < IT; ++it) {
 #pragma unroll
         for (int m = 16; m <= 32; m <<= 1) {
             double ov[1] = {__shfl_xor(best[it].v[0], m, 64)};
@@ -2095,21 +2103,37 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         DBGSOM_HIP_CHECK(hipEventRecord(side.forked, s));
         DBGSOM_HIP_CHECK(hipStreamWaitEvent(s2, side.forked, 0));
     }
-#define DBGSOM_SUBSET(JTL, STREAM)                                                                \
+#define DBGSOM_SUBSET_W(JTL, NWV_, STREAM)                                                        \
     do {                                                                                          \
         if (x_dtype == DBGSOM_F32)                                                                \
-            hipLaunchKernelGGL((subset_exact_kernel<float, JTL>), dim3((unsigned)f.nb), dim3(NT), 0, STREAM, \
+            hipLaunchKernelGGL((subset_exact_kernel<float, JTL, NWV_>), dim3((unsigned)f.nb), dim3(NWV_ * 64), 0, STREAM, \
                                (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
                                order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
         else                                                                                      \
-            hipLaunchKernelGGL((subset_exact_kernel<double, JTL>), dim3((unsigned)f.nb), dim3(NT), 0, STREAM, \
+            hipLaunchKernelGGL((subset_exact_kernel<double, JTL, NWV_>), dim3((unsigned)f.nb), dim3(NWV_ * 64), 0, STREAM, \
                                (const double *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
                                order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
+    } while (0)
+    // Wavefronts per workgroup of the exact stage: 4 x 32 samples or 8 x 16 (half the accumulators:
+    // class 3 goes from 3 to 6 wavefronts per SIMD).  Measured (ms per stage, 4 / 8 / class 3 only):
+    // C4 1.23 / 1.23 / 1.16, C3 0.52 / 0.48, C5 shard 5.83 / 5.33 -- 8 for the long lists, 4 for the
+    // rest.  DBGSOM_EXACT_WAVES = 4 | 8 | two digits (class 3, classes 2 and 1).
+    static const int exact_waves = [] {
+        const char *e = getenv("DBGSOM_EXACT_WAVES");
+        return e ? atoi(e) : 84;
+    }();
+    // (two digits: class 3, then classes 2 and 1)
+#define DBGSOM_SUBSET(JTL, STREAM)                                                                \
+    do {                                                                                          \
+        const int w_ = exact_waves >= 10 ? (JTL == 3 ? exact_waves / 10 : exact_waves % 10) : exact_waves; \
+        if (w_ == 8) DBGSOM_SUBSET_W(JTL, 8, STREAM);                                             \
+        else DBGSOM_SUBSET_W(JTL, 4, STREAM);                                                     \
     } while (0)
     DBGSOM_SUBSET(3, s);
     DBGSOM_SUBSET(2, s2);
     DBGSOM_SUBSET(1, s2);
 #undef DBGSOM_SUBSET
+#undef DBGSOM_SUBSET_W
 #undef DBGSOM_SWEEP
 #undef S4_LAUNCH
     if (fork) {
