@@ -19,14 +19,30 @@ struct SmoothWs {
     double *den;    // M
     double *rowchg; // M
     int32_t *rank;  // M       rank among non-empty neurons
+    double *part;   // splits x M x d   partial products of the split-K GEMM (splits > 1)
 };
+
+// The GEMM's grid is ceil(d / 64) x ceil(M / 64) workgroups, each walking all M / 16 k-tiles one
+// after the other: on a map of ~1000 neurons that is fewer workgroups than CUs and a 64-tile
+// dependent chain.  The k range is therefore cut into `splits` consecutive pieces (a function of
+// the shape alone) computed side by side and added in piece order: still bitwise reproducible.
+static int gemm_splits(int64_t M, int64_t d) {
+    const int64_t tiles = ((d + 63) / 64) * ((M + 63) / 64), nkt = (M + 15) / 16;
+    int64_t ks = (768 + tiles - 1) / tiles;
+    if (ks > 8) ks = 8;
+    if (ks > nkt / 4) ks = nkt / 4;
+    return (int)(ks < 1 ? 1 : ks);
+}
 
 static size_t carve_smooth(SmoothWs *w, char *base, int64_t M, int64_t d) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t oC = take((size_t)M * d * 8), oG = take((size_t)M * M * 8);
     const size_t oD = take((size_t)M * 8), oR = take((size_t)M * 8), oK = take((size_t)M * 4);
+    const int ks = gemm_splits(M, d);
+    const size_t oP = take(ks > 1 ? (size_t)ks * M * d * 8 : 0);
     if (w) {
+        w->part = (double *)(base + oP);
         w->C = (double *)(base + oC); w->G = (double *)(base + oG);
         w->den = (double *)(base + oD); w->rowchg = (double *)(base + oR);
         w->rank = (int32_t *)(base + oK);
@@ -103,13 +119,18 @@ constexpr int GT = 64, GK = 16, GS_A = GK + 2, GS_B = GT + 16;
 __global__ __launch_bounds__(256) void smooth_gemm_kernel(const double *__restrict__ G,
                                                           const double *__restrict__ C,
                                                           const double *__restrict__ den, int M,
-                                                          int d, double *__restrict__ Wn) {
+                                                          int d, int splits,
+                                                          double *__restrict__ part,
+                                                          double *__restrict__ Wn) {
     __shared__ double gs[GT * GS_A];   // [i][j]   rows padded to 18: conflict-free A fragments
     __shared__ double cs[GK * GS_B];   // [j][c]   rows padded to 80: conflict-free B fragments
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 wavefronts, 32 x 32 outputs each
     const int lr = lane & 15, lq = lane >> 4;
     const int i0 = blockIdx.y * GT, c0 = blockIdx.x * GT;
+    // this workgroup's piece of the k range (whole k-tiles)
+    const int per = ((M + GK - 1) / GK + splits - 1) / splits * GK;
+    const int jlo = blockIdx.z * per, jhi = min(M, jlo + per);
     sd4_t acc[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -126,14 +147,14 @@ __global__ __launch_bounds__(256) void smooth_gemm_kernel(const double *__restri
             const int e = t + 256 * u;
             const int r = e / GK, k = e % GK;  // G tile: 64 rows x 16 j
             const int gi = i0 + r, gj = j0 + k;
-            gr[u] = (gi < M && gj < M) ? G[(size_t)gi * M + gj] : 0.0;
+            gr[u] = (gi < M && gj < jhi) ? G[(size_t)gi * M + gj] : 0.0;
             const int kr = e / GT, cc = e % GT;  // C tile: 16 j x 64 cols
             const int cj = j0 + kr, col = c0 + cc;
-            cr[u] = (cj < M && col < d) ? C[(size_t)cj * d + col] : 0.0;
+            cr[u] = (cj < jhi && col < d) ? C[(size_t)cj * d + col] : 0.0;
         }
     };
-    fetch(0);
-    for (int j0 = 0; j0 < M; j0 += GK) {
+    fetch(jlo);
+    for (int j0 = jlo; j0 < jhi; j0 += GK) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -142,7 +163,7 @@ __global__ __launch_bounds__(256) void smooth_gemm_kernel(const double *__restri
             cs[(e / GT) * GS_B + e % GT] = cr[u];
         }
         __syncthreads();
-        if (j0 + GK < M) fetch(j0 + GK);
+        if (j0 + GK < jhi) fetch(j0 + GK);
 #pragma unroll
         for (int ks = 0; ks < GK / 4; ++ks) {
             double a[2], b[2];
@@ -169,20 +190,35 @@ __global__ __launch_bounds__(256) void smooth_gemm_kernel(const double *__restri
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
                 const int c = c0 + wc * 32 + v * 16 + lr;
-                if (c < d) Wn[(size_t)i * d + c] = acc[u][v][r] / dn;
+                if (c >= d) continue;
+                if (splits == 1) Wn[(size_t)i * d + c] = acc[u][v][r] / dn;
+                else part[((size_t)blockIdx.z * M + i) * d + c] = acc[u][v][r];
             }
         }
 }
 
-// rowchg[i] = |W_i - W'_i|_2
+// rowchg[i] = |W_i - W'_i|_2; with a split-K GEMM, W'_i is first put together from the pieces (in
+// piece order) and divided by den[i]
 __global__ __launch_bounds__(256) void rowchange_kernel(const double *__restrict__ Wo,
-                                                        const double *__restrict__ Wn, int d,
+                                                        double *__restrict__ Wn, int M, int d,
+                                                        int splits, const double *__restrict__ part,
+                                                        const double *__restrict__ den,
                                                         double *__restrict__ rowchg) {
     __shared__ double red[256];
     const int i = blockIdx.x, t = threadIdx.x;
     double s = 0.0;
+    const double dn = den[i];
     for (int c = t; c < d; c += 256) {
-        const double df = Wo[(size_t)i * d + c] - Wn[(size_t)i * d + c];
+        double wn;
+        if (splits == 1) {
+            wn = Wn[(size_t)i * d + c];
+        } else {
+            double p = part[(size_t)i * d + c];
+            for (int z = 1; z < splits; ++z) p += part[((size_t)z * M + i) * d + c];
+            wn = p / dn;
+            Wn[(size_t)i * d + c] = wn;
+        }
+        const double df = Wo[(size_t)i * d + c] - wn;
         s += df * df;
     }
     red[t] = s;
@@ -234,10 +270,12 @@ int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, do
                        layout, w.C);
     hipLaunchKernelGGL(neighbourhood_kernel, dim3((unsigned)M), dim3(256), 0, s, hop, a, Mi,
                        2.0 * (sigma * sigma), w.G, w.den);
-    dim3 grid((unsigned)((d + GT - 1) / GT), (unsigned)((M + GT - 1) / GT));
-    hipLaunchKernelGGL(smooth_gemm_kernel, grid, dim3(256), 0, s, w.G, w.C, w.den, Mi, di, W_new);
-    hipLaunchKernelGGL(rowchange_kernel, dim3((unsigned)M), dim3(256), 0, s, W_old, W_new, di,
-                       w.rowchg);
+    const int splits = gemm_splits(M, d);
+    dim3 grid((unsigned)((d + GT - 1) / GT), (unsigned)((M + GT - 1) / GT), (unsigned)splits);
+    hipLaunchKernelGGL(smooth_gemm_kernel, grid, dim3(256), 0, s, w.G, w.C, w.den, Mi, di, splits,
+                       w.part, W_new);
+    hipLaunchKernelGGL(rowchange_kernel, dim3((unsigned)M), dim3(256), 0, s, W_old, W_new, Mi, di,
+                       splits, w.part, w.den, w.rowchg);
     hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1024), 0, s, w.rowchg, Mi, change_total);
     return launch_status("smooth kernels");
 }
