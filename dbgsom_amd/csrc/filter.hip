@@ -44,7 +44,8 @@ constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
 #ifndef SWEEP_EXPERIMENT
 #define SWEEP_EXPERIMENT 0  // 4 no MFMA, 8 no chunk epilogue,
 // 64 (with 8) products dead, 256 in-kernel s_memtime stamps (tools/sweep_stamps.py), 512 passing
-// pairs (tools/sweep_survivors.py), 1024 stamps in sweep4_i8_kernel (tools/sweep4_stamps.py)
+// pairs (tools/sweep_survivors.py), 1024 stamps in sweep4_i8_kernel (tools/sweep4_stamps.py),
+// 2048 sweep4_i8_kernel reads the fragments of every second k-step only (LDS share of its time)
 #endif
 
 // plane rows are padded to whole k-tiles, at least two of them (the sweep's ring runs three tiles
@@ -1193,6 +1194,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
     struct Frags { v4i_t x[2], w[JT]; };
     auto load_frags = [&](int stage_off, int ks, Frags &f) {
         const char *stage = smem + stage_off;
+#if SWEEP_EXPERIMENT & 2048
+        if (ks == 1) {  // timing experiment: half of the fragment reads (results are wrong)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) f.w[jt] = f.x[jt & 1];
+            return;
+        }
+#endif
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt)
             f.w[jt] = *reinterpret_cast<const v4i_t *>(stage + (woff[jt] ^ (ks * 32)));
