@@ -335,7 +335,9 @@ __global__ __launch_bounds__(AT) void finalize_kernel(const double *__restrict__
     const uint32_t c0 = min(b1, b0 + g * per), c1 = min(b1, c0 + per);
     double *S = sums + (size_t)j * d;
     double *Kp = sums + (size_t)M * d, *ap = Kp + M, *Ep = ap + M;
-    for (int col = threadIdx.x; col < d + 2; col += AT) {
+    // (the column blocks of a neuron are separate workgroups, gridDim.z of them: one short chain
+    // per thread instead of four one after the other)
+    for (int col = threadIdx.x + AT * blockIdx.z; col < d + 2; col += AT * gridDim.z) {
         double s = 0.0;
         uint32_t c = c0;
         for (; c + 8 <= c1; c += 8) {  // loads batched, additions still in chunk order
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(AT) void finalize_kernel(const double *__restrict__
         else if (col == d) Kp[j] = s;
         else Ep[j] = s;
     }
-    if (threadIdx.x == 0 && g == 0) ap[j] = (double)count[j];
+    if (threadIdx.x == 0 && g == 0 && blockIdx.z == 0) ap[j] = (double)count[j];
 }
 
 // second level (NG > 1): the NG group sums of a neuron in group order
@@ -453,7 +455,8 @@ int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t 
     }
 #undef DBGSOM_SEGSUM
     const int NG = finalize_groups(M);
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)M, (unsigned)NG), dim3(AT), 0, s, w.slab, di, Mi,
+    const unsigned col_blocks = (unsigned)((d + 2 + AT - 1) / AT < 8 ? (d + 2 + AT - 1) / AT : 8);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)M, (unsigned)NG, col_blocks), dim3(AT), 0, s, w.slab, di, Mi,
                        w.count, w.chunk_pre, NG, w.gslab, sums);
     if (NG > 1)
         hipLaunchKernelGGL(finalize_groups_kernel, dim3((unsigned)M), dim3(AT), 0, s, w.gslab, di, Mi, NG,
