@@ -16,6 +16,14 @@ LIB_PATH = os.environ.get("DBGSOM_LIB") or os.path.join(CSRC, "libdbgsom_hip.so"
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "dbgsom_hip.h")
 
 F32, F64, BF16 = 0, 1, 2
+ALG_AUTO, ALG_EXACT, ALG_FILTERED, ALG_FILTERED_HINT = 0, 1, 2, 3
+ALGORITHMS = {"auto": ALG_AUTO, "exact": ALG_EXACT, "filtered": ALG_FILTERED,
+              "filtered_hint": ALG_FILTERED_HINT}
+EPOCH_FROZEN = 1
+ABI_VERSION = 2
+# int (*)(void *user, double *buf_dev, int64_t count, void *stream)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                ctypes.c_void_p)
 CENTRES_COMPACT, CENTRES_ALIGNED = 0, 1
 LAYOUTS = {"compact": CENTRES_COMPACT, "aligned": CENTRES_ALIGNED}
 MAX_PROTOTYPES = 16000
@@ -54,11 +62,37 @@ SIGNATURES = {
     "dbgsom_class_histogram": (_ci, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dbgsom_ctx_create": (_ci, [_ci, ctypes.POINTER(_vp)]),
     "dbgsom_ctx_destroy": (_ci, [_vp]),
-    "dbgsom_ctx_load": (_ci, [_vp, _vp, _ci, _i64, _i64]),
+    "dbgsom_ctx_set_option": (_ci, [_vp, ctypes.c_char_p, _i64]),
+    "dbgsom_ctx_get_option": (_ci, [_vp, ctypes.c_char_p, ctypes.POINTER(_i64)]),
+    "dbgsom_ctx_stream": (_ci, [_vp, ctypes.POINTER(_vp)]),
+    "dbgsom_ctx_load": (_ci, [_vp, _vp, _ci, _i64, _i64, _ci]),
+    "dbgsom_ctx_load_device": (_ci, [_vp, _vp, _ci, _i64, _i64, _i64]),
+    "dbgsom_ctx_read_samples": (_ci, [_vp, _vp, _i64, _vp]),
+    "dbgsom_ctx_set_labels": (_ci, [_vp, _vp, _i64]),
     "dbgsom_ctx_set_topology": (_ci, [_vp, _vp, _i64]),
+    "dbgsom_ctx_set_allreduce": (_ci, [_vp, _vp, _vp]),
+    "dbgsom_ctx_set_weights": (_ci, [_vp, _vp, _i64]),
+    "dbgsom_ctx_get_weights": (_ci, [_vp, _ci, _vp, _i64]),
+    "dbgsom_ctx_read_weight_rows": (_ci, [_vp, _ci, _vp, _i64, _vp]),
+    "dbgsom_ctx_write_weight_rows": (_ci, [_vp, _i64, _i64, _vp]),
     "dbgsom_ctx_bmu": (_ci, [_vp, _vp, _i64, _ci, _ci, _vp, _vp]),
     "dbgsom_ctx_bmu_query": (_ci, [_vp, _vp, _ci, _i64, _i64, _vp, _i64, _ci, _ci, _vp, _vp]),
-    "dbgsom_ctx_epoch": (_ci, [_vp, _vp, _i64, _ci, _dbl, _dbl, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dbgsom_ctx_exp_similarity": (_ci, [_vp, _vp, _i64, _dbl, _vp]),
+    "dbgsom_ctx_epoch": (_ci, [_vp, _vp, _i64, _ci, _dbl, _dbl, _ci, _ci, _vp, _vp, _vp, _vp, _vp,
+                               _vp]),
+    "dbgsom_ctx_update": (_ci, [_vp, _vp, _i64, _vp, _vp, _vp, _dbl, _ci, _vp, _vp, _vp, _vp]),
+    "dbgsom_ctx_set_hint": (_ci, [_vp, _vp, _i64]),
+    "dbgsom_ctx_read_sums": (_ci, [_vp, _vp, _i64]),
+    "dbgsom_ctx_column_sums": (_ci, [_vp, _vp, _vp]),
+    "dbgsom_ctx_quantization_error": (_ci, [_vp, _vp, _i64, _ci, _vp]),
+    "dbgsom_ctx_topographic_count": (_ci, [_vp, _vp, _i64, _ci, _vp, _vp]),
+    "dbgsom_ctx_node_statistics": (_ci, [_vp, _vp, _i64, _ci, _dbl, _vp, _vp]),
+    "dbgsom_ctx_class_histogram": (_ci, [_vp, _vp, _i64, _i64, _vp]),
+    "dbgsom_ctx_partition": (_ci, [_vp, _vp, _i64, _ci, _vp, _vp]),
+    "dbgsom_ctx_subset_create": (_ci, [_vp, _i64, ctypes.POINTER(_vp)]),
+    "dbgsom_ctx_epoch_info": (_ci, [_vp, _vp]),
+    "dbgsom_ctx_filter_counts": (_ci, [_vp, _vp, _i64]),
+    "dbgsom_ctx_phase_ms": (_ci, [_vp, _vp]),
 }
 
 _lib = None
@@ -123,8 +157,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dbgsom_abi_version() != 1:
-        raise RuntimeError(f"ABI version mismatch: library {lib.dbgsom_abi_version()}, binding 1")
+    if lib.dbgsom_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"ABI version mismatch: library {lib.dbgsom_abi_version()}, "
+                           f"binding {ABI_VERSION} (rebuild: make -C dbgsom_amd/csrc)")
     _lib = lib
     return lib
 

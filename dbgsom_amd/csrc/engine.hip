@@ -1,0 +1,1249 @@
+// Context-level C ABI (include/dbgsom_hip.h, "Context-level entry points"): the host engine of the
+// batch-SOM hot path.  A context owns one GPU's share of the job -- the resident samples (padded,
+// optionally bfloat16), their norms and int8 digit planes, the prototypes, every workspace -- and
+// runs the epoch body of BaseSom._grow_som (reference dbgsom/BaseSom.py:403-407) as one blocking
+// call.  What used to be Python policy lives here: feature padding, the choice between the
+// all-pairs and the filtered BMU search ("auto" / back-off), the adaptive number of digit planes,
+// previous winners as seeds, device-resident prototypes between epochs, the one all-reduce per
+// epoch (through the caller's callback).  No kernels of the hot path in this file: it drives the
+// launchers of bmu*.hip, filter.hip, accumulate.hip, smooth.hip, stats.hip.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace dbgsom {
+
+// a device allocation that grows on demand and is reused across calls
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return DBGSOM_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();
+            set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return DBGSOM_ENOMEM;
+        }
+        cap = want;
+        return DBGSOM_OK;
+    }
+    // grow and keep the first `keep` bytes (ordered on `s`)
+    int reserve_keep(size_t bytes, size_t keep, hipStream_t s) {
+        if (bytes <= cap) return DBGSOM_OK;
+        void *old = p;
+        p = nullptr;
+        cap = 0;
+        const int rc = reserve(bytes * 2);
+        if (rc != DBGSOM_OK) { p = old; return rc; }
+        if (old && keep) {
+            hipError_t e = hipMemcpyAsync(p, old, keep, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { set_error("device copy failed: %s", hipGetErrorString(e)); (void)hipFree(old); return DBGSOM_EHIP; }
+        }
+        if (old) (void)hipFree(old);
+        return DBGSOM_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// page-locked host staging for the small per-epoch results
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return DBGSOM_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = align_up(bytes * 2, 4096);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return DBGSOM_ENOMEM; }
+        cap = want;
+        return DBGSOM_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ---- small helper kernels ----------------------------------------------------------------------
+// float32 -> bfloat16 (round to nearest even, NaN stays NaN) and back: the rows that stay resident
+// and the exactly widened copy the BMU kernels read
+__global__ void round_bf16_kernel(float *__restrict__ x, uint16_t *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t u = __float_as_uint(x[i]);
+        uint16_t b;
+        if ((u & 0x7fffffffu) > 0x7f800000u) b = 0x7fc0;
+        else b = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        out[i] = b;
+        x[i] = __uint_as_float(((uint32_t)b) << 16);
+    }
+}
+__global__ void widen_bf16_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = __uint_as_float(((uint32_t)in[i]) << 16);
+}
+__global__ void f64_to_f32_kernel(const double *__restrict__ in, float *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+__global__ void u64_to_f64_kernel(const unsigned long long *__restrict__ in, double *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (double)in[i];
+}
+__global__ void status_to_f64_kernel(const int32_t *__restrict__ status, double *__restrict__ out) {
+    out[0] = status[0] ? 1.0 : 0.0;
+}
+// rows of a (rows x ld) matrix of element size ES gathered by index, 16 bytes per thread where aligned
+template <typename T>
+__global__ void gather_rows_kernel(const T *__restrict__ src, int64_t ld, const int32_t *__restrict__ ids,
+                                   int64_t first, int64_t n, int64_t cols, T *__restrict__ dst) {
+    const int64_t r = blockIdx.x;
+    if (r >= n) return;
+    const T *s = src + (int64_t)ids[first + r] * ld;
+    T *d = dst + r * cols;
+    for (int64_t c = threadIdx.x; c < cols; c += blockDim.x) d[c] = s[c];
+}
+__global__ void gather_i32_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ ids, int64_t first,
+                                  int64_t n, int32_t *__restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[ids[first + i]];
+}
+template <typename T>
+__global__ void rows_to_f64_kernel(const T *__restrict__ src, int64_t ld, const int64_t *__restrict__ ids, int64_t n,
+                                   int64_t cols, double *__restrict__ dst) {
+    const int64_t r = blockIdx.x;
+    if (r >= n) return;
+    const T *s = src + ids[r] * ld;
+    for (int64_t c = threadIdx.x; c < cols; c += blockDim.x) dst[r * cols + c] = widen(s[c]);
+}
+__global__ void seg_counts_kernel(const uint32_t *__restrict__ seg_start, int64_t M, int64_t N, int64_t *__restrict__ counts) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (int64_t)gridDim.x * blockDim.x)
+        counts[j] = (int64_t)((j + 1 < M ? seg_start[j + 1] : (uint32_t)N) - seg_start[j]);
+}
+
+static unsigned grid1d(int64_t n, int block = 256) {
+    const int64_t nb = (n + block - 1) / block;
+    return (unsigned)(nb < 1 ? 1 : (nb > 8192 ? 8192 : nb));
+}
+
+}  // namespace dbgsom
+
+using namespace dbgsom;
+
+// the device-level ABI the engine drives (defined in filter.hip / stats.hip)
+extern "C" {
+size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d);
+size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M);
+}
+
+namespace {
+
+constexpr int64_t FILTER_MIN_PROTOTYPES = 129;  // at or below 128 one chunk of the all-pairs kernel is cheaper (measured)
+constexpr int64_t FILTER_MAX_FEATURES = 43690;  // int32 digit-product accumulators: 3 x 128 x 128 x d < 2^31
+constexpr int FILTER_BACKOFF = 8;
+constexpr int PLANES_REPROBE = 64;
+// cost model of the candidate sweep (per prototype) against a list entry of the exact stage
+const double SWEEP_COST[4] = {0.0, 0.54, 1.0, 1.96};
+constexpr double LIST_COST = 16.4;
+
+struct Samples {  // one resident sample set (training samples, or a query batch)
+    int dtype = -1;            // storage dtype in HBM
+    int64_t N = 0, d = 0, dp = 0;
+    const void *X = nullptr;   // N x dp, storage dtype (own.p or borrowed)
+    const void *Xb = nullptr;  // what the BMU kernels read: X, or the float32 copy of bfloat16 rows
+    int bdtype = -1;
+    DevBuf own, x32, xx, planes;
+    bool planes_ready = false;
+    void release() { own.release(); x32.release(); xx.release(); planes.release(); planes_ready = false; dtype = -1; N = 0; X = Xb = nullptr; }
+};
+
+}  // namespace
+
+struct dbgsom_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // options
+    int algorithm = DBGSOM_ALG_AUTO;
+    int sweep_planes = 0;
+    int seed_stride = 0;
+    int timing = 0;
+    int use_graph = 0;
+    int64_t filter_min_query_rows = 32768;
+    int64_t max_mean_candidates = 320;
+    // samples
+    Samples xs, xq;
+    DevBuf y;
+    bool has_labels = false;
+    // topology
+    int64_t topoM = 0;
+    DevBuf hop, hop_stage;
+    // prototypes: two M x dp float64 buffers
+    DevBuf Wb[2];
+    int cur = 0;
+    int64_t M = 0;       // rows of the resident prototypes (Wb[cur])
+    int64_t otherM = 0;  // rows of Wb[cur ^ 1]
+    // per-epoch device state
+    DevBuf ww, idx[2], dist, kw, sums, acc_ws, sm_ws, filt_ws, scal, qidx, qdist, red, hist, stage_dev;
+    int icur = 0;            // idx[icur]: winners of the last epoch (the hint)
+    bool hint_valid = false;
+    int64_t hintM = 0;
+    bool last_idx_valid = false;  // idx[icur] holds the winners of the last epoch / partition
+    int64_t sumsM = 0;
+    // partition (vertical growth)
+    DevBuf part_order, part_ws, part_counts;
+    int64_t partM = 0;
+    bool part_valid = false;
+    // policy
+    int filter_backoff = 0, filter_fail = 0;
+    int planes_next = 1, planes_used = 1;
+    int64_t planeM = -1;
+    double plane_known[4] = {NAN, NAN, NAN, NAN};
+    int plane_hold = 0;
+    // last epoch
+    bool last_filtered = false, last_hinted = false;
+    double last_mean = NAN;
+    int64_t last_filter_M = 0, last_filter_N = 0, last_filter_d = 0;
+    const void *last_filter_ws = nullptr;
+    // staging
+    PinBuf tail, counts;
+    // collective
+    dbgsom_allreduce_fn allreduce = nullptr;
+    void *allreduce_user = nullptr;
+    // timing
+    hipEvent_t ev[4] = {};
+    bool ev_created = false, ev_valid = false;
+    double filter_ms[5] = {0, 0, 0, 0, 0};
+    bool filter_ms_valid = false;
+};
+
+extern "C" {
+int dbgsom_filter_timing(int enable);
+int dbgsom_bmu_filtered_stage_ms(double *ms5);
+}
+
+namespace {
+
+#define CTX_CHECK(c)                                                                 \
+    do {                                                                             \
+        if (!(c)) { set_error("%s: null context", __func__); return DBGSOM_EINVAL; } \
+        DBGSOM_HIP_CHECK(hipSetDevice((c)->device));                                 \
+    } while (0)
+#define TRY(expr) do { int _rc = (expr); if (_rc != DBGSOM_OK) return _rc; } while (0)
+
+inline int64_t pad16(int64_t d) { return (d + 15) / 16 * 16; }
+
+int sync(dbgsom_ctx *c) {
+    DBGSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return DBGSOM_OK;
+}
+
+// host (rows x d, element size es) -> device (rows x dp), zeros behind column d
+int upload_padded(dbgsom_ctx *c, void *dst, const void *src, int64_t rows, int64_t d, int64_t dp, size_t es) {
+    if (rows == 0) return DBGSOM_OK;
+    if (d == dp) {
+        DBGSOM_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)rows * d * es, hipMemcpyHostToDevice, c->stream));
+    } else {
+        DBGSOM_HIP_CHECK(hipMemsetAsync(dst, 0, (size_t)rows * dp * es, c->stream));
+        DBGSOM_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)dp * es, src, (size_t)d * es, (size_t)d * es, (size_t)rows,
+                                          hipMemcpyHostToDevice, c->stream));
+    }
+    return DBGSOM_OK;
+}
+
+int download_unpadded(dbgsom_ctx *c, void *dst, const void *src, int64_t rows, int64_t d, int64_t dp, size_t es) {
+    if (rows == 0) return DBGSOM_OK;
+    if (d == dp)
+        DBGSOM_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)rows * d * es, hipMemcpyDeviceToHost, c->stream));
+    else
+        DBGSOM_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)d * es, src, (size_t)dp * es, (size_t)d * es, (size_t)rows,
+                                          hipMemcpyDeviceToHost, c->stream));
+    return DBGSOM_OK;
+}
+
+// norms + BMU view of a freshly placed sample set (s.X, s.dtype, s.N, s.d, s.dp set)
+int finish_samples(dbgsom_ctx *c, Samples &s, bool x32_is_widened) {
+    if (s.dtype == DBGSOM_BF16) {
+        if (!x32_is_widened) {
+            TRY(s.x32.reserve((size_t)s.N * s.dp * 4));
+            hipLaunchKernelGGL(widen_bf16_kernel, dim3(grid1d(s.N * s.dp)), dim3(256), 0, c->stream,
+                               (const uint16_t *)s.X, s.x32.as<float>(), s.N * s.dp);
+            TRY(launch_status("widen_bf16_kernel"));
+        }
+        s.Xb = s.x32.p;
+        s.bdtype = DBGSOM_F32;
+    } else {
+        s.Xb = s.X;
+        s.bdtype = s.dtype;
+    }
+    TRY(s.xx.reserve((size_t)s.N * 8));
+    TRY(launch_row_sqnorms(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), c->stream));
+    s.planes_ready = false;
+    return DBGSOM_OK;
+}
+
+int place_host_samples(dbgsom_ctx *c, Samples &s, const void *X_host, int x_dtype, int64_t N, int64_t d, int storage) {
+    DBGSOM_REQUIRE(valid_dtype(x_dtype) && valid_dtype(storage), "dtype must be DBGSOM_F32/F64/BF16");
+    DBGSOM_REQUIRE(X_host && N >= 1 && d >= 1 && N < 0x7fffffff, "bad samples");
+    DBGSOM_REQUIRE(storage == x_dtype || (storage == DBGSOM_BF16 && x_dtype == DBGSOM_F32),
+                   "storage must be the input dtype, or DBGSOM_BF16 for float32 input");
+    const int64_t dp = pad16(d);
+    s.N = N; s.d = d; s.dp = dp; s.dtype = storage;
+    bool widened = false;
+    if (storage == DBGSOM_BF16 && x_dtype == DBGSOM_F32) {
+        TRY(s.x32.reserve((size_t)N * dp * 4));
+        TRY(s.own.reserve((size_t)N * dp * 2));
+        TRY(upload_padded(c, s.x32.p, X_host, N, d, dp, 4));
+        hipLaunchKernelGGL(round_bf16_kernel, dim3(grid1d(N * dp)), dim3(256), 0, c->stream, s.x32.as<float>(),
+                           s.own.as<uint16_t>(), N * dp);
+        TRY(launch_status("round_bf16_kernel"));
+        widened = true;
+    } else {
+        const size_t es = dtype_size(x_dtype);
+        TRY(s.own.reserve((size_t)N * dp * es));
+        TRY(upload_padded(c, s.own.p, X_host, N, d, dp, es));
+    }
+    s.X = s.own.p;
+    return finish_samples(c, s, widened);
+}
+
+int ensure_planes(dbgsom_ctx *c, Samples &s) {
+    if (s.planes_ready) return DBGSOM_OK;
+    const size_t nbytes = dbgsom_filter_planes_bytes(s.N, s.dp);
+    TRY(s.planes.reserve(nbytes));
+    TRY(dbgsom_filter_prepare(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.planes.p, s.planes.cap, c->stream));
+    s.planes_ready = true;
+    return DBGSOM_OK;
+}
+
+bool filter_shape_ok(const Samples &s, int64_t M) {
+    return M >= FILTER_MIN_PROTOTYPES && M <= DBGSOM_MAX_PROTOTYPES && s.dp <= FILTER_MAX_FEATURES && s.N >= 1;
+}
+
+bool filter_applies(const dbgsom_ctx *c, int64_t M) {
+    if (c->algorithm == DBGSOM_ALG_EXACT) return false;
+    if (c->algorithm == DBGSOM_ALG_AUTO && c->filter_backoff > 0) return false;
+    return filter_shape_ok(c->xs, M);
+}
+
+int planes_for_call(const dbgsom_ctx *c) { return c->sweep_planes ? c->sweep_planes : c->planes_next; }
+
+// prototypes: make W (host, or the resident ones) the consumed matrix Wb[cur]; norms into ww
+int stage_weights(dbgsom_ctx *c, const double *W_host, int64_t M, int64_t d, int64_t dp) {
+    DBGSOM_REQUIRE(M >= 1 && M <= 0x7fffff00, "bad prototype count");
+    if (W_host) {
+        TRY(c->Wb[c->cur].reserve((size_t)M * dp * 8));
+        TRY(upload_padded(c, c->Wb[c->cur].p, W_host, M, d, dp, 8));
+        c->M = M;
+    } else if (c->M != M) {
+        set_error("no resident prototypes of %lld rows (resident: %lld); pass W_host or call dbgsom_ctx_set_weights",
+                  (long long)M, (long long)c->M);
+        return DBGSOM_ESTATE;
+    }
+    TRY(c->ww.reserve((size_t)M * 8));
+    return launch_row_sqnorms(c->Wb[c->cur].p, DBGSOM_F64, M, dp, dp, c->ww.as<double>(), c->stream);
+}
+
+// k = 1 search through the int8 filter; seeds = previous winners when `hinted`
+int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t M, int round_f32,
+                 const int64_t *prev_idx, const int32_t *order, int64_t *idx, double *dist) {
+    TRY(ensure_planes(c, s));
+    TRY(ws.reserve(dbgsom_bmu_filtered_workspace_bytes(s.N, s.dp, M)));
+    c->planes_used = planes_for_call(c);
+    TRY(dbgsom_bmu_filtered(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), s.planes.p, W, M,
+                            c->ww.as<double>(), prev_idx, order, c->seed_stride, c->planes_used, round_f32, idx,
+                            dist, ws.p, ws.cap, c->stream));
+    c->last_filter_M = M; c->last_filter_N = s.N; c->last_filter_d = s.dp; c->last_filter_ws = ws.p;
+    return DBGSOM_OK;
+}
+
+int run_allreduce(dbgsom_ctx *c, double *buf, int64_t count) {
+    if (!c->allreduce) return DBGSOM_OK;
+    const int rc = c->allreduce(c->allreduce_user, buf, count, (void *)c->stream);
+    if (rc != 0) {
+        (void)hipStreamSynchronize(c->stream);
+        set_error("all-reduce callback failed (%d)", rc);
+        return DBGSOM_ECALLBACK;
+    }
+    return DBGSOM_OK;
+}
+
+void adapt_planes(dbgsom_ctx *c, double mean, int64_t M) {
+    const int p = c->planes_used;
+    if (c->planeM != M) {  // another map size: what was learnt no longer applies
+        c->planeM = M;
+        for (double &k : c->plane_known) k = NAN;
+        c->plane_hold = 0;
+    }
+    c->plane_known[p] = mean;
+    if (c->plane_hold > 0) {
+        if (--c->plane_hold == 0) {  // forget the alternatives, they get another look
+            for (double &k : c->plane_known) k = NAN;
+            c->plane_known[p] = mean;
+        }
+        return;
+    }
+    auto cost = [&](int q) { return SWEEP_COST[q] * (double)M + LIST_COST * c->plane_known[q]; };
+    int best = 0;
+    for (int q = 1; q <= 3; ++q)
+        if (!isnan(c->plane_known[q]) && (best == 0 || cost(q) < cost(best))) best = q;
+    // a finer sweep can at best empty the lists; a coarser one is simply tried
+    const int finer = best + 1, coarser = best - 1;
+    if (finer <= 3 && isnan(c->plane_known[finer]) &&
+        LIST_COST * c->plane_known[best] > (SWEEP_COST[finer] - SWEEP_COST[best]) * (double)M)
+        c->planes_next = finer;
+    else if (coarser >= 1 && isnan(c->plane_known[coarser]))
+        c->planes_next = coarser;
+    else {
+        c->planes_next = best;
+        c->plane_hold = PLANES_REPROBE;
+    }
+}
+
+// after an epoch has completed: look at how long the candidate lists were, decide what comes next
+void update_policy(dbgsom_ctx *c, const uint32_t *counts, int64_t nb, int64_t M) {
+    if (!c->last_filtered) { c->last_mean = NAN; return; }
+    double sum = 0.0;
+    for (int64_t b = 0; b < nb; ++b) sum += counts[b];
+    const double mean = nb ? sum / (double)nb : 0.0;
+    c->last_mean = mean;
+    if (c->sweep_planes == 0) adapt_planes(c, mean, M);
+    if (c->algorithm == DBGSOM_ALG_AUTO) {
+        if (mean > (double)c->max_mean_candidates) {  // exponential back-off, capped
+            c->filter_fail = c->filter_fail < 6 ? c->filter_fail + 1 : 6;
+            c->filter_backoff = FILTER_BACKOFF << (c->filter_fail - 1);
+        } else {
+            c->filter_fail = 0;
+        }
+    }
+}
+
+void mark(dbgsom_ctx *c, int k) {
+    if (!c->timing) return;
+    if (!c->ev_created) { for (auto &e : c->ev) (void)hipEventCreate(&e); c->ev_created = true; }
+    (void)hipEventRecord(c->ev[k], c->stream);
+}
+
+// BMU (k = 1) of the resident samples under Wb[cur] into idx[icur ^ 1] / dist, by policy
+int epoch_bmu(dbgsom_ctx *c, int64_t M, int round_f32) {
+    Samples &s = c->xs;
+    TRY(c->idx[0].reserve((size_t)s.N * 8));
+    TRY(c->idx[1].reserve((size_t)s.N * 8));
+    TRY(c->dist.reserve((size_t)s.N * 8));
+    int64_t *out = c->idx[c->icur ^ 1].as<int64_t>();
+    const double *W = c->Wb[c->cur].as<double>();
+    c->last_hinted = false;
+    if (filter_applies(c, M)) {
+        const bool hint = (c->algorithm == DBGSOM_ALG_AUTO || c->algorithm == DBGSOM_ALG_FILTERED_HINT) &&
+                          c->hint_valid && c->hintM <= M;
+        c->last_filtered = true;
+        c->last_hinted = hint;
+        TRY(run_filtered(c, s, c->filt_ws, W, M, round_f32, hint ? c->idx[c->icur].as<int64_t>() : nullptr,
+                         hint ? c->acc_ws.as<int32_t>() : nullptr, out, c->dist.as<double>()));
+    } else {
+        c->last_filtered = false;
+        if (c->filter_backoff > 0) --c->filter_backoff;
+        TRY(launch_bmu(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), W, M, c->ww.as<double>(), 1, round_f32,
+                       out, c->dist.as<double>(), c->stream));
+    }
+    c->icur ^= 1;
+    c->hint_valid = false;  // re-established by the accumulate step that follows
+    c->last_idx_valid = true;
+    return DBGSOM_OK;
+}
+
+// sums = [S | K | a | E | status] of the resident samples for winners idx / weights kw / distances dist
+int accumulate_and_reduce(dbgsom_ctx *c, const int64_t *idx, const double *kw, const double *dist, int64_t M) {
+    Samples &s = c->xs;
+    DBGSOM_REQUIRE(M <= DBGSOM_MAX_PROTOTYPES, "M exceeds DBGSOM_MAX_PROTOTYPES");
+    const int64_t count = M * (s.dp + 3);
+    TRY(c->sums.reserve((size_t)(count + 1) * 8));
+    TRY(c->acc_ws.reserve(accumulate_workspace_bytes(s.N, s.dp, M)));
+    TRY(c->scal.reserve(256));
+    int32_t *status = reinterpret_cast<int32_t *>(c->scal.as<char>() + 64);
+    c->part_valid = false;
+    TRY(launch_accumulate(s.X, s.dtype, s.N, s.dp, s.dp, idx, kw, dist, M, c->sums.as<double>(), status,
+                          c->acc_ws.p, c->acc_ws.cap, c->stream));
+    hipLaunchKernelGGL(status_to_f64_kernel, dim3(1), dim3(1), 0, c->stream, status, c->sums.as<double>() + count);
+    TRY(launch_status("status_to_f64_kernel"));
+    c->sumsM = M;
+    return run_allreduce(c, c->sums.as<double>(), count + 1);
+}
+
+// smoothing of the reduced sums: Wb[cur] -> Wb[cur ^ 1]; queues the small results D2H and waits
+int smooth_and_fetch(dbgsom_ctx *c, int64_t M, double sigma, int layout, int flags, double *W_new_host,
+                     double *change_total_host, double *errors_host, double *activations_host,
+                     const int64_t *idx_dev, int64_t *idx_host, double *dist_host) {
+    Samples &s = c->xs;
+    const int64_t dp = s.dp, d = s.d;
+    if (c->topoM != M) {
+        set_error("topology holds %lld neurons, prototypes %lld (call dbgsom_ctx_set_topology after growth)",
+                  (long long)c->topoM, (long long)M);
+        return DBGSOM_ESTATE;
+    }
+    const int nxt = c->cur ^ 1;
+    TRY(c->Wb[nxt].reserve((size_t)M * dp * 8));
+    TRY(c->sm_ws.reserve(smooth_workspace_bytes(M, dp)));
+    double *chg = c->scal.as<double>();
+    double *sums = c->sums.as<double>();
+    TRY(launch_smooth(sums, M, dp, c->hop.as<float>(), sigma, layout, c->Wb[c->cur].as<double>(),
+                      c->Wb[nxt].as<double>(), chg, c->sm_ws.p, c->sm_ws.cap, c->stream));
+    mark(c, 3);
+    // the epoch's small results come back in ONE round trip: queued copies into pinned memory, one
+    // stream synchronisation
+    const int64_t nb = (s.N + 127) / 128;
+    TRY(c->tail.reserve((size_t)(2 * M + 2) * 8));
+    double *tail = c->tail.as<double>();
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(tail, sums + (size_t)M * dp + M, (size_t)2 * M * 8, hipMemcpyDeviceToHost, c->stream));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(tail + 2 * M, chg, 8, hipMemcpyDeviceToHost, c->stream));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(tail + 2 * M + 1, sums + (size_t)M * (dp + 3), 8, hipMemcpyDeviceToHost, c->stream));
+    if (c->last_filtered) {
+        TRY(c->counts.reserve((size_t)nb * 4));
+        TRY(dbgsom_bmu_filtered_counts_async(c->filt_ws.p, s.N, dp, M, c->counts.as<uint32_t>(), nb, c->stream));
+    }
+    if (W_new_host) TRY(download_unpadded(c, W_new_host, c->Wb[nxt].p, M, d, dp, 8));
+    if (idx_host) DBGSOM_HIP_CHECK(hipMemcpyAsync(idx_host, idx_dev, (size_t)s.N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (dist_host) DBGSOM_HIP_CHECK(hipMemcpyAsync(dist_host, c->dist.p, (size_t)s.N * 8, hipMemcpyDeviceToHost, c->stream));
+    TRY(sync(c));
+    c->ev_valid = c->timing != 0;
+    if (c->timing && c->last_filtered) {
+        c->filter_ms_valid = dbgsom_bmu_filtered_stage_ms(c->filter_ms) == DBGSOM_OK;
+    } else {
+        c->filter_ms_valid = false;
+    }
+    memcpy(activations_host, tail, (size_t)M * 8);
+    memcpy(errors_host, tail + M, (size_t)M * 8);
+    change_total_host[0] = tail[2 * M];
+    c->otherM = M;
+    if (!(flags & DBGSOM_EPOCH_FROZEN)) c->cur = nxt;  // W' becomes the resident matrix, W the "previous" one
+    if (tail[2 * M + 1] != 0.0) { set_error("winner index out of range"); return DBGSOM_ERANGE; }
+    return DBGSOM_OK;
+}
+
+int loaded(const dbgsom_ctx *c, const char *fn) {
+    if (c->xs.dtype < 0) { set_error("%s: no samples loaded", fn); return DBGSOM_ESTATE; }
+    return DBGSOM_OK;
+}
+
+// BMU of the resident samples for the reductions around the path: k = 1 by policy, k = 2 all-pairs.
+// Results in qidx / qdist (N x k); the training hint (idx[icur], bucket order) is left alone.
+int resident_bmu(dbgsom_ctx *c, const double *W_host, int64_t M, int k, int round_f32) {
+    Samples &s = c->xs;
+    TRY(stage_weights(c, W_host, M, s.d, s.dp));
+    TRY(c->qidx.reserve((size_t)s.N * k * 8));
+    TRY(c->qdist.reserve((size_t)s.N * k * 8));
+    const double *W = c->Wb[c->cur].as<double>();
+    if (k == 1 && filter_applies(c, M)) {
+        const bool hint = (c->algorithm == DBGSOM_ALG_AUTO || c->algorithm == DBGSOM_ALG_FILTERED_HINT) &&
+                          c->hint_valid && c->hintM <= M;
+        return run_filtered(c, s, c->filt_ws, W, M, round_f32, hint ? c->idx[c->icur].as<int64_t>() : nullptr,
+                            hint ? c->acc_ws.as<int32_t>() : nullptr, c->qidx.as<int64_t>(), c->qdist.as<double>());
+    }
+    return launch_bmu(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), W, M, c->ww.as<double>(), k, round_f32,
+                      c->qidx.as<int64_t>(), c->qdist.as<double>(), c->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------
+// life cycle, options
+// ------------------------------------------------------------------------------------------
+int dbgsom_ctx_create(int device, dbgsom_ctx **out) {
+    DBGSOM_REQUIRE(out, "null pointer");
+    *out = nullptr;
+    int n = 0;
+    DBGSOM_HIP_CHECK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) {
+        set_error("dbgsom_ctx_create: device %d not available (%d visible)", device, n);
+        return DBGSOM_EINVAL;
+    }
+    DBGSOM_HIP_CHECK(hipSetDevice(device));
+    dbgsom_ctx *c = new (std::nothrow) dbgsom_ctx();
+    if (!c) { set_error("out of host memory"); return DBGSOM_ENOMEM; }
+    c->device = device;
+    const char *e = getenv("DBGSOM_SWEEP_PLANES");  // diagnostic: fixes the digit planes of every context
+    if (e) { const int v = atoi(e); if (v >= 0 && v <= 3) c->sweep_planes = v; }
+    hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (err != hipSuccess) {
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(err));
+        delete c;
+        return DBGSOM_EHIP;
+    }
+    *out = c;
+    return DBGSOM_OK;
+}
+
+int dbgsom_ctx_destroy(dbgsom_ctx *c) {
+    if (!c) return DBGSOM_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->timing) (void)dbgsom_filter_timing(0);
+    c->xs.release(); c->xq.release();
+    DevBuf *bufs[] = {&c->y, &c->hop, &c->hop_stage, &c->Wb[0], &c->Wb[1], &c->ww, &c->idx[0], &c->idx[1],
+                      &c->dist, &c->kw, &c->sums, &c->acc_ws, &c->sm_ws, &c->filt_ws, &c->scal, &c->qidx,
+                      &c->qdist, &c->red, &c->hist, &c->stage_dev, &c->part_order, &c->part_ws, &c->part_counts};
+    for (DevBuf *b : bufs) b->release();
+    c->tail.release(); c->counts.release();
+    if (c->ev_created) for (auto &e : c->ev) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return DBGSOM_OK;
+}
+
+int dbgsom_ctx_set_option(dbgsom_ctx *c, const char *name, int64_t v) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(name, "null option name");
+    if (!strcmp(name, "algorithm")) {
+        DBGSOM_REQUIRE(v >= DBGSOM_ALG_AUTO && v <= DBGSOM_ALG_FILTERED_HINT, "algorithm must be a DBGSOM_ALG_* value");
+        c->algorithm = (int)v;
+    } else if (!strcmp(name, "sweep_planes")) {
+        DBGSOM_REQUIRE(v >= 0 && v <= 3, "sweep_planes must be 0 .. 3");
+        c->sweep_planes = (int)v;
+    } else if (!strcmp(name, "seed_stride")) {
+        DBGSOM_REQUIRE(v >= 0 && v <= 64, "seed_stride outside [0, 64]");
+        c->seed_stride = (int)v;
+    } else if (!strcmp(name, "timing")) {
+        c->timing = v != 0;
+        c->ev_valid = false;
+        TRY(dbgsom_filter_timing(c->timing));
+    } else if (!strcmp(name, "graph")) {
+        c->use_graph = v != 0;
+    } else if (!strcmp(name, "filter_min_query_rows")) {
+        DBGSOM_REQUIRE(v >= 0, "filter_min_query_rows must be >= 0");
+        c->filter_min_query_rows = v;
+    } else if (!strcmp(name, "max_mean_candidates")) {
+        DBGSOM_REQUIRE(v >= 1, "max_mean_candidates must be >= 1");
+        c->max_mean_candidates = v;
+    } else {
+        set_error("dbgsom_ctx_set_option: unknown option '%s'", name);
+        return DBGSOM_EINVAL;
+    }
+    return DBGSOM_OK;
+}
+
+int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(name && v, "null pointer");
+    if (!strcmp(name, "algorithm")) *v = c->algorithm;
+    else if (!strcmp(name, "sweep_planes")) *v = c->sweep_planes;
+    else if (!strcmp(name, "seed_stride")) *v = c->seed_stride;
+    else if (!strcmp(name, "timing")) *v = c->timing;
+    else if (!strcmp(name, "graph")) *v = c->use_graph;
+    else if (!strcmp(name, "filter_min_query_rows")) *v = c->filter_min_query_rows;
+    else if (!strcmp(name, "max_mean_candidates")) *v = c->max_mean_candidates;
+    else if (!strcmp(name, "n_samples")) *v = c->xs.dtype < 0 ? 0 : c->xs.N;
+    else if (!strcmp(name, "features")) *v = c->xs.dtype < 0 ? 0 : c->xs.d;
+    else if (!strcmp(name, "padded_features")) *v = c->xs.dtype < 0 ? 0 : c->xs.dp;
+    else if (!strcmp(name, "storage")) *v = c->xs.dtype;
+    else if (!strcmp(name, "prototypes")) *v = c->M;
+    else if (!strcmp(name, "planes_cached")) *v = c->xs.planes_ready ? 1 : 0;
+    else if (!strcmp(name, "planes_used")) *v = c->planes_used;
+    else if (!strcmp(name, "planes_next")) *v = planes_for_call(c);
+    else if (!strcmp(name, "hint_valid")) *v = c->hint_valid ? 1 : 0;
+    else if (!strcmp(name, "filter_backoff")) *v = c->filter_backoff;
+    else if (!strcmp(name, "plane_hold")) *v = c->plane_hold;
+    else if (!strcmp(name, "device_bytes")) {
+        size_t tot = c->xs.own.cap + c->xs.x32.cap + c->xs.xx.cap + c->xs.planes.cap + c->xq.own.cap + c->xq.x32.cap +
+                     c->xq.xx.cap + c->xq.planes.cap;
+        DevBuf *bufs[] = {&c->y, &c->hop, &c->hop_stage, &c->Wb[0], &c->Wb[1], &c->ww, &c->idx[0], &c->idx[1],
+                          &c->dist, &c->kw, &c->sums, &c->acc_ws, &c->sm_ws, &c->filt_ws, &c->scal, &c->qidx,
+                          &c->qdist, &c->red, &c->hist, &c->stage_dev, &c->part_order, &c->part_ws, &c->part_counts};
+        for (DevBuf *b : bufs) tot += b->cap;
+        *v = (int64_t)tot;
+    } else {
+        set_error("dbgsom_ctx_get_option: unknown option '%s'", name);
+        return DBGSOM_EINVAL;
+    }
+    return DBGSOM_OK;
+}
+
+int dbgsom_ctx_stream(dbgsom_ctx *c, void **stream) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(stream, "null pointer");
+    *stream = (void *)c->stream;
+    return DBGSOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// residency
+// ------------------------------------------------------------------------------------------
+static void reset_training_state(dbgsom_ctx *c) {
+    c->hint_valid = c->last_idx_valid = c->part_valid = false;
+    c->has_labels = false;
+    c->filter_backoff = c->filter_fail = 0;
+    c->planes_next = 1;
+    c->planeM = -1;
+    c->plane_hold = 0;
+    c->last_filtered = false;
+    c->last_mean = NAN;
+    c->sumsM = 0;
+}
+
+int dbgsom_ctx_load(dbgsom_ctx *c, const void *X_host, int x_dtype, int64_t N, int64_t d, int storage) {
+    CTX_CHECK(c);
+    reset_training_state(c);
+    c->xs.dtype = -1;
+    const int rc = place_host_samples(c, c->xs, X_host, x_dtype, N, d, storage);
+    if (rc != DBGSOM_OK) { (void)hipStreamSynchronize(c->stream); c->xs.dtype = -1; return rc; }
+    return sync(c);
+}
+
+int dbgsom_ctx_load_device(dbgsom_ctx *c, const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(valid_dtype(x_dtype), "x_dtype must be DBGSOM_F32/F64/BF16");
+    DBGSOM_REQUIRE(X_dev && N >= 1 && d >= 1 && ldx >= d && N < 0x7fffffff, "bad samples");
+    reset_training_state(c);
+    Samples &s = c->xs;
+    const size_t es = dtype_size(x_dtype);
+    const int64_t dp = pad16(d);
+    s.dtype = -1;
+    s.N = N; s.d = d; s.dp = dp;
+    if (ldx == dp && d == dp && is_aligned(X_dev, 16)) {
+        s.own.release();
+        s.X = X_dev;  // borrowed
+    } else {
+        TRY(s.own.reserve((size_t)N * dp * es));
+        if (d != dp) DBGSOM_HIP_CHECK(hipMemsetAsync(s.own.p, 0, (size_t)N * dp * es, c->stream));
+        DBGSOM_HIP_CHECK(hipMemcpy2DAsync(s.own.p, (size_t)dp * es, X_dev, (size_t)ldx * es, (size_t)d * es, (size_t)N,
+                                          hipMemcpyDeviceToDevice, c->stream));
+        s.X = s.own.p;
+    }
+    s.dtype = x_dtype;
+    const int rc = finish_samples(c, s, false);
+    if (rc != DBGSOM_OK) { (void)hipStreamSynchronize(c->stream); s.dtype = -1; return rc; }
+    return sync(c);
+}
+
+int dbgsom_ctx_read_samples(dbgsom_ctx *c, const int64_t *rows_host, int64_t n, double *out_host) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(n >= 0 && (n == 0 || (rows_host && out_host)), "bad arguments");
+    if (n == 0) return DBGSOM_OK;
+    Samples &s = c->xs;
+    for (int64_t r = 0; r < n; ++r) DBGSOM_REQUIRE(rows_host[r] >= 0 && rows_host[r] < s.N, "row index out of range");
+    TRY(c->stage_dev.reserve((size_t)n * 8 + (size_t)n * s.d * 8 + 256));
+    int64_t *ids = c->stage_dev.as<int64_t>();
+    double *rows = reinterpret_cast<double *>(c->stage_dev.as<char>() + align_up((size_t)n * 8));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(ids, rows_host, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if (s.dtype == DBGSOM_F32)
+        hipLaunchKernelGGL(rows_to_f64_kernel<float>, dim3((unsigned)n), dim3(256), 0, c->stream, (const float *)s.X, s.dp, ids, n, s.d, rows);
+    else if (s.dtype == DBGSOM_F64)
+        hipLaunchKernelGGL(rows_to_f64_kernel<double>, dim3((unsigned)n), dim3(256), 0, c->stream, (const double *)s.X, s.dp, ids, n, s.d, rows);
+    else
+        hipLaunchKernelGGL(rows_to_f64_kernel<bf16_t>, dim3((unsigned)n), dim3(256), 0, c->stream, (const bf16_t *)s.X, s.dp, ids, n, s.d, rows);
+    TRY(launch_status("rows_to_f64_kernel"));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(out_host, rows, (size_t)n * s.d * 8, hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
+}
+
+int dbgsom_ctx_set_labels(dbgsom_ctx *c, const int32_t *y_host, int64_t N) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    if (!y_host) { c->has_labels = false; return DBGSOM_OK; }
+    DBGSOM_REQUIRE(N == c->xs.N, "one label per resident sample");
+    TRY(c->y.reserve((size_t)N * 4));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(c->y.p, y_host, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    c->has_labels = true;
+    return sync(c);
+}
+
+int dbgsom_ctx_set_topology(dbgsom_ctx *c, const double *hop_host, int64_t M) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(hop_host && M >= 1 && M <= DBGSOM_MAX_PROTOTYPES, "bad topology");
+    const int64_t n = M * M;
+    TRY(c->hop_stage.reserve((size_t)n * 8));
+    TRY(c->hop.reserve((size_t)n * 4));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(c->hop_stage.p, hop_host, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(grid1d(n)), dim3(256), 0, c->stream, c->hop_stage.as<double>(),
+                       c->hop.as<float>(), n);
+    TRY(launch_status("f64_to_f32_kernel"));
+    TRY(sync(c));
+    c->topoM = M;
+    return DBGSOM_OK;
+}
+
+int dbgsom_ctx_set_allreduce(dbgsom_ctx *c, dbgsom_allreduce_fn fn, void *user) {
+    CTX_CHECK(c);
+    c->allreduce = fn;
+    c->allreduce_user = user;
+    return DBGSOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// prototypes
+// ------------------------------------------------------------------------------------------
+int dbgsom_ctx_set_weights(dbgsom_ctx *c, const double *W_host, int64_t M) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(W_host && M >= 1, "bad prototypes");
+    TRY(c->Wb[c->cur].reserve((size_t)M * c->xs.dp * 8));
+    TRY(upload_padded(c, c->Wb[c->cur].p, W_host, M, c->xs.d, c->xs.dp, 8));
+    c->M = M;
+    return sync(c);
+}
+
+int dbgsom_ctx_get_weights(dbgsom_ctx *c, int which, double *W_host, int64_t M) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(W_host && (which == 0 || which == 1), "bad arguments");
+    const int b = which ? c->cur ^ 1 : c->cur;
+    const int64_t have = which ? c->otherM : c->M;
+    if (have != M || M < 1) {
+        set_error("dbgsom_ctx_get_weights: buffer %d holds %lld rows, %lld asked for", which, (long long)have, (long long)M);
+        return DBGSOM_ESTATE;
+    }
+    TRY(download_unpadded(c, W_host, c->Wb[b].p, M, c->xs.d, c->xs.dp, 8));
+    return sync(c);
+}
+
+int dbgsom_ctx_read_weight_rows(dbgsom_ctx *c, int which, const int64_t *rows_host, int64_t n, double *out_host) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE((which == 0 || which == 1) && n >= 0 && (n == 0 || (rows_host && out_host)), "bad arguments");
+    const int b = which ? c->cur ^ 1 : c->cur;
+    const int64_t have = which ? c->otherM : c->M;
+    const int64_t d = c->xs.d, dp = c->xs.dp;
+    for (int64_t r = 0; r < n; ++r) {
+        DBGSOM_REQUIRE(rows_host[r] >= 0 && rows_host[r] < have, "row index out of range");
+        DBGSOM_HIP_CHECK(hipMemcpyAsync(out_host + r * d, c->Wb[b].as<double>() + rows_host[r] * dp, (size_t)d * 8,
+                                        hipMemcpyDeviceToHost, c->stream));
+    }
+    return sync(c);
+}
+
+int dbgsom_ctx_write_weight_rows(dbgsom_ctx *c, int64_t row0, int64_t n, const double *rows_host) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(n >= 0 && row0 >= 0 && row0 <= c->M && (n == 0 || rows_host), "rows must lie in [0, M] (row0 == M appends)");
+    if (n == 0) return DBGSOM_OK;
+    const int64_t d = c->xs.d, dp = c->xs.dp;
+    const int64_t newM = row0 + n > c->M ? row0 + n : c->M;
+    TRY(c->Wb[c->cur].reserve_keep((size_t)newM * dp * 8, (size_t)c->M * dp * 8, c->stream));
+    double *dst = c->Wb[c->cur].as<double>() + row0 * dp;
+    TRY(upload_padded(c, dst, rows_host, n, d, dp, 8));
+    c->M = newM;
+    return sync(c);
+}
+
+// ------------------------------------------------------------------------------------------
+// BMU
+// ------------------------------------------------------------------------------------------
+int dbgsom_ctx_bmu(dbgsom_ctx *c, const double *W_host, int64_t M, int k, int round_f32, int64_t *idx_host,
+                   double *dist_host) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(idx_host && dist_host && (k == 1 || k == 2), "bad arguments");
+    DBGSOM_REQUIRE(M >= k, "need k <= M");
+    TRY(resident_bmu(c, W_host, M, k, round_f32));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(idx_host, c->qidx.p, (size_t)c->xs.N * k * 8, hipMemcpyDeviceToHost, c->stream));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(dist_host, c->qdist.p, (size_t)c->xs.N * k * 8, hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
+}
+
+int dbgsom_ctx_bmu_query(dbgsom_ctx *c, const void *Xq_host, int x_dtype, int64_t Nq, int64_t d, const double *W_host,
+                         int64_t M, int k, int round_f32, int64_t *idx_host, double *dist_host) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(valid_dtype(x_dtype), "x_dtype must be DBGSOM_F32/F64/BF16");
+    DBGSOM_REQUIRE(Xq_host && W_host && idx_host && dist_host && Nq >= 0 && d >= 1 && M >= 1 && (k == 1 || k == 2) && M >= k,
+                   "bad arguments");
+    if (Nq == 0) return DBGSOM_OK;
+    Samples &s = c->xq;
+    DevBuf Wq, wwq, iq, dq, fws;  // query-sized scratch; independent of the training state
+    int rc = DBGSOM_OK;
+    const int64_t dp = pad16(d);
+    do {
+        if ((rc = place_host_samples(c, s, Xq_host, x_dtype, Nq, d, x_dtype))) break;
+        if ((rc = Wq.reserve((size_t)M * dp * 8))) break;
+        if ((rc = wwq.reserve((size_t)M * 8))) break;
+        if ((rc = iq.reserve((size_t)Nq * k * 8))) break;
+        if ((rc = dq.reserve((size_t)Nq * k * 8))) break;
+        if ((rc = upload_padded(c, Wq.p, W_host, M, d, dp, 8))) break;
+        if ((rc = launch_row_sqnorms(Wq.p, DBGSOM_F64, M, dp, dp, wwq.as<double>(), c->stream))) break;
+        // large k = 1 queries go through the filter (the digit planes of a one-off X cost a pass over it)
+        const bool filt = k == 1 && c->algorithm != DBGSOM_ALG_EXACT && Nq >= c->filter_min_query_rows &&
+                          filter_shape_ok(s, M);
+        if (filt) {
+            if ((rc = ensure_planes(c, s))) break;
+            if ((rc = fws.reserve(dbgsom_bmu_filtered_workspace_bytes(Nq, dp, M)))) break;
+            const int planes = planes_for_call(c);
+            rc = dbgsom_bmu_filtered(s.Xb, s.bdtype, Nq, dp, dp, s.xx.as<double>(), s.planes.p, Wq.as<double>(), M,
+                                     wwq.as<double>(), nullptr, nullptr, c->seed_stride, planes, round_f32,
+                                     iq.as<int64_t>(), dq.as<double>(), fws.p, fws.cap, c->stream);
+        } else {
+            rc = launch_bmu(s.Xb, s.bdtype, Nq, dp, dp, s.xx.as<double>(), Wq.as<double>(), M, wwq.as<double>(), k,
+                            round_f32, iq.as<int64_t>(), dq.as<double>(), c->stream);
+        }
+        if (rc) break;
+        hipError_t e = hipMemcpyAsync(idx_host, iq.p, (size_t)Nq * k * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dist_host, dq.p, (size_t)Nq * k * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { set_error("D2H copy failed: %s", hipGetErrorString(e)); rc = DBGSOM_EHIP; }
+    } while (0);
+    if (rc != DBGSOM_OK) (void)hipStreamSynchronize(c->stream);
+    Wq.release(); wwq.release(); iq.release(); dq.release(); fws.release();
+    if (Nq * dp * (int64_t)dtype_size(x_dtype) > ((int64_t)256 << 20)) s.release();  // do not sit on a large one-off batch
+    return rc;
+}
+
+int dbgsom_ctx_exp_similarity(dbgsom_ctx *c, const double *dist_host, int64_t n, double gamma, double *kw_host) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(n >= 0 && (n == 0 || (dist_host && kw_host)), "bad arguments");
+    if (n == 0) return DBGSOM_OK;
+    TRY(c->stage_dev.reserve((size_t)2 * n * 8));
+    double *din = c->stage_dev.as<double>(), *dout = din + n;
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(din, dist_host, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_exp_similarity(din, n, gamma, dout, c->stream));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(kw_host, dout, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
+}
+
+// ------------------------------------------------------------------------------------------
+// the epoch
+// ------------------------------------------------------------------------------------------
+int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f32, double gamma, double sigma,
+                     int layout, int flags, double *W_new_host, double *change_total_host, double *errors_host,
+                     double *activations_host, int64_t *idx_host, double *dist_host) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(change_total_host && errors_host && activations_host, "null output");
+    DBGSOM_REQUIRE(layout == DBGSOM_CENTRES_COMPACT || layout == DBGSOM_CENTRES_ALIGNED, "bad layout");
+    if (c->topoM != M) {
+        set_error("dbgsom_ctx_epoch: topology holds %lld neurons, weights %lld (call "
+                  "dbgsom_ctx_set_topology after growth)", (long long)c->topoM, (long long)M);
+        return DBGSOM_ESTATE;
+    }
+    Samples &s = c->xs;
+    int rc = DBGSOM_OK;
+    do {
+        if ((rc = stage_weights(c, W_host, M, s.d, s.dp))) break;
+        mark(c, 0);
+        if ((rc = epoch_bmu(c, M, round_f32))) break;
+        mark(c, 1);
+        const int64_t *idx = c->idx[c->icur].as<int64_t>();
+        if ((rc = c->kw.reserve((size_t)s.N * 8))) break;
+        if ((rc = launch_exp_similarity(c->dist.as<double>(), s.N, gamma, c->kw.as<double>(), c->stream))) break;
+        if ((rc = accumulate_and_reduce(c, idx, c->kw.as<double>(), c->dist.as<double>(), M))) break;
+        // the next epoch's filter visits the samples bucketed by this epoch's winners: the stable
+        // counting sort the accumulate step just did (first N int32 of its workspace)
+        c->hint_valid = true;
+        c->hintM = M;
+        mark(c, 2);
+        rc = smooth_and_fetch(c, M, sigma, layout, flags, W_new_host, change_total_host, errors_host, activations_host,
+                              idx, idx_host, dist_host);
+        if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) break;
+        update_policy(c, c->counts.as<uint32_t>(), (s.N + 127) / 128, M);
+    } while (0);
+    if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) { (void)hipStreamSynchronize(c->stream); c->hint_valid = false; }
+    return rc;
+}
+
+int dbgsom_ctx_update(dbgsom_ctx *c, const double *W_host, int64_t M, const int64_t *idx_host, const double *kw_host,
+                      const double *dist_host, double sigma, int layout, double *W_new_host,
+                      double *change_total_host, double *errors_host, double *activations_host) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(idx_host && kw_host && dist_host && change_total_host && errors_host && activations_host, "null pointer");
+    DBGSOM_REQUIRE(layout == DBGSOM_CENTRES_COMPACT || layout == DBGSOM_CENTRES_ALIGNED, "bad layout");
+    Samples &s = c->xs;
+    int rc = DBGSOM_OK;
+    do {
+        if ((rc = stage_weights(c, W_host, M, s.d, s.dp))) break;
+        if ((rc = c->idx[0].reserve((size_t)s.N * 8))) break;
+        if ((rc = c->idx[1].reserve((size_t)s.N * 8))) break;
+        if ((rc = c->dist.reserve((size_t)s.N * 8))) break;
+        if ((rc = c->kw.reserve((size_t)s.N * 8))) break;
+        c->hint_valid = false;
+        c->icur ^= 1;
+        int64_t *idx = c->idx[c->icur].as<int64_t>();
+        hipError_t e = hipMemcpyAsync(idx, idx_host, (size_t)s.N * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->kw.p, kw_host, (size_t)s.N * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->dist.p, dist_host, (size_t)s.N * 8, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { set_error("H2D copy failed: %s", hipGetErrorString(e)); rc = DBGSOM_EHIP; break; }
+        c->last_filtered = false;
+        c->last_idx_valid = true;
+        if ((rc = accumulate_and_reduce(c, idx, c->kw.as<double>(), c->dist.as<double>(), M))) break;
+        rc = smooth_and_fetch(c, M, sigma, layout, 0, W_new_host, change_total_host, errors_host, activations_host, idx,
+                              nullptr, nullptr);
+    } while (0);
+    if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) (void)hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+int dbgsom_ctx_set_hint(dbgsom_ctx *c, const int64_t *idx_host, int64_t M) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(idx_host && M >= 1 && M <= DBGSOM_MAX_PROTOTYPES, "bad arguments");
+    Samples &s = c->xs;
+    for (int64_t i = 0; i < s.N; ++i) DBGSOM_REQUIRE(idx_host[i] >= 0 && idx_host[i] < M, "seed index out of range");
+    TRY(c->idx[0].reserve((size_t)s.N * 8));
+    TRY(c->idx[1].reserve((size_t)s.N * 8));
+    // the bucket order lives where the accumulate step leaves it: the first N int32 of its workspace
+    TRY(c->acc_ws.reserve(accumulate_workspace_bytes(s.N, s.dp, M)));
+    TRY(c->part_ws.reserve(bucket_sort_workspace_bytes(s.N, M)));
+    int64_t *idx = c->idx[c->icur].as<int64_t>();
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(idx, idx_host, (size_t)s.N * 8, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_bucket_sort(idx, s.N, M, c->acc_ws.as<int32_t>(), c->part_ws.p, c->stream));
+    TRY(sync(c));
+    c->hint_valid = true;
+    c->hintM = M;
+    c->part_valid = false;
+    return DBGSOM_OK;
+}
+
+int dbgsom_ctx_read_sums(dbgsom_ctx *c, double *sums_host, int64_t M) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(sums_host, "null pointer");
+    if (c->sumsM != M || M < 1) { set_error("dbgsom_ctx_read_sums: no sums of %lld neurons", (long long)M); return DBGSOM_ESTATE; }
+    const int64_t d = c->xs.d, dp = c->xs.dp;
+    TRY(download_unpadded(c, sums_host, c->sums.p, M, d, dp, 8));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(sums_host + M * d, c->sums.as<double>() + M * dp, (size_t)3 * M * 8,
+                                    hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
+}
+
+// ------------------------------------------------------------------------------------------
+// reductions around the path
+// ------------------------------------------------------------------------------------------
+int dbgsom_ctx_column_sums(dbgsom_ctx *c, const void *mean_host, void *out_host) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(out_host, "null pointer");
+    Samples &s = c->xs;
+    DBGSOM_REQUIRE(s.dtype == DBGSOM_F32 || s.dtype == DBGSOM_F64, "float32 / float64 resident samples only");
+    const size_t es = dtype_size(s.dtype);
+    TRY(c->stage_dev.reserve((size_t)2 * s.dp * es + 512));
+    char *mean_dev = c->stage_dev.as<char>();
+    char *out_dev = mean_dev + align_up((size_t)s.dp * es);
+    if (mean_host) {
+        DBGSOM_HIP_CHECK(hipMemsetAsync(mean_dev, 0, (size_t)s.dp * es, c->stream));
+        DBGSOM_HIP_CHECK(hipMemcpyAsync(mean_dev, mean_host, (size_t)s.d * es, hipMemcpyHostToDevice, c->stream));
+    }
+    TRY(dbgsom_column_sums(s.X, s.dtype, s.N, s.dp, s.dp, mean_host ? mean_dev : nullptr, out_dev, c->stream));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(out_host, out_dev, (size_t)s.d * es, hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
+}
+
+static int reduce_small(dbgsom_ctx *c, double *buf_dev, int64_t n, double *out_host) {
+    TRY(run_allreduce(c, buf_dev, n));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(out_host, buf_dev, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
+}
+
+int dbgsom_ctx_quantization_error(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f32, double *out2) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(out2, "null pointer");
+    TRY(resident_bmu(c, W_host, M, 1, round_f32));
+    TRY(c->red.reserve(256 + dbgsom_sum_workspace_bytes()));
+    double *r = c->red.as<double>();
+    TRY(dbgsom_sum_f64(c->qdist.as<double>(), c->xs.N, r, c->red.as<char>() + 256, c->red.cap - 256, c->stream));
+    const double n = (double)c->xs.N;
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(r + 1, &n, 8, hipMemcpyHostToDevice, c->stream));
+    return reduce_small(c, r, 2, out2);
+}
+
+int dbgsom_ctx_topographic_count(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f32, const int32_t *xy_host,
+                                 double *count_host) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(xy_host && count_host && M >= 2, "bad arguments");
+    TRY(resident_bmu(c, W_host, M, 2, round_f32));
+    TRY(c->red.reserve(256 + (size_t)M * 8));
+    int32_t *xy = reinterpret_cast<int32_t *>(c->red.as<char>() + 256);
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(xy, xy_host, (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
+    uint64_t *cnt = reinterpret_cast<uint64_t *>(c->red.as<char>() + 64);
+    TRY(dbgsom_topographic_count(c->qidx.as<int64_t>(), c->xs.N, xy, M, cnt, c->stream));
+    double *r = c->red.as<double>();
+    hipLaunchKernelGGL(u64_to_f64_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long *)cnt, r, (int64_t)1);
+    TRY(launch_status("u64_to_f64_kernel"));
+    return reduce_small(c, r, 1, count_host);
+}
+
+int dbgsom_ctx_node_statistics(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f32, double sigma,
+                               double *hits_host, double *density_host) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(hits_host && density_host && sigma > 0.0, "bad arguments");
+    Samples &s = c->xs;
+    TRY(resident_bmu(c, W_host, M, 1, round_f32));
+    TRY(c->kw.reserve((size_t)s.N * 8));
+    TRY(dbgsom_density_terms(c->qdist.as<double>(), s.N, sigma, c->kw.as<double>(), c->stream));
+    // K = density sums, a = hit counts of the fused buffer; the bucket order of the training hint is rewritten
+    c->hint_valid = false;
+    DBGSOM_REQUIRE(M <= DBGSOM_MAX_PROTOTYPES, "M exceeds DBGSOM_MAX_PROTOTYPES");
+    const int64_t count = M * (s.dp + 3);
+    TRY(c->sums.reserve((size_t)(count + 1) * 8));
+    TRY(c->acc_ws.reserve(accumulate_workspace_bytes(s.N, s.dp, M)));
+    c->part_valid = false;
+    c->sumsM = 0;
+    TRY(launch_accumulate(s.X, s.dtype, s.N, s.dp, s.dp, c->qidx.as<int64_t>(), c->kw.as<double>(), c->qdist.as<double>(), M,
+                          c->sums.as<double>(), nullptr, c->acc_ws.p, c->acc_ws.cap, c->stream));
+    double *tail = c->sums.as<double>() + M * s.dp;  // [K | a]
+    TRY(run_allreduce(c, tail, 2 * M));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(density_host, tail, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(hits_host, tail + M, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
+}
+
+int dbgsom_ctx_class_histogram(dbgsom_ctx *c, const int64_t *idx_host, int64_t n_classes, int64_t M, int64_t *hist_host) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(hist_host && n_classes >= 1 && M >= 1, "bad arguments");
+    if (!c->has_labels) { set_error("class histogram requested but no labels attached (dbgsom_ctx_set_labels)"); return DBGSOM_ESTATE; }
+    Samples &s = c->xs;
+    const int64_t *idx = nullptr;
+    if (idx_host) {
+        TRY(c->qidx.reserve((size_t)s.N * 8));
+        DBGSOM_HIP_CHECK(hipMemcpyAsync(c->qidx.p, idx_host, (size_t)s.N * 8, hipMemcpyHostToDevice, c->stream));
+        idx = c->qidx.as<int64_t>();
+    } else {
+        if (!c->last_idx_valid) { set_error("no winners of a previous epoch in HBM"); return DBGSOM_ESTATE; }
+        idx = c->idx[c->icur].as<int64_t>();
+    }
+    const int64_t n = M * n_classes;
+    TRY(c->hist.reserve((size_t)2 * n * 8));
+    uint64_t *h = c->hist.as<uint64_t>();
+    double *hd = c->hist.as<double>() + n;
+    TRY(dbgsom_class_histogram(idx, c->y.as<int32_t>(), s.N, M, n_classes, h, c->stream));
+    hipLaunchKernelGGL(u64_to_f64_kernel, dim3(grid1d(n)), dim3(256), 0, c->stream, (const unsigned long long *)h, hd, n);
+    TRY(launch_status("u64_to_f64_kernel"));
+    TRY(run_allreduce(c, hd, n));
+    std::vector<double> tmp;
+    try { tmp.resize((size_t)n); } catch (...) { set_error("out of host memory"); return DBGSOM_ENOMEM; }
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(tmp.data(), hd, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    TRY(sync(c));
+    for (int64_t e = 0; e < n; ++e) hist_host[e] = (int64_t)llround(tmp[(size_t)e]);
+    return DBGSOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// vertical growth
+// ------------------------------------------------------------------------------------------
+int dbgsom_ctx_partition(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f32, int64_t *counts_host,
+                         int64_t *idx_host) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(counts_host && M >= 1 && M <= DBGSOM_MAX_PROTOTYPES, "bad arguments");
+    Samples &s = c->xs;
+    TRY(resident_bmu(c, W_host, M, 1, round_f32));
+    TRY(c->part_order.reserve((size_t)s.N * 4));
+    TRY(c->part_ws.reserve(bucket_sort_workspace_bytes(s.N, M)));
+    TRY(c->part_counts.reserve((size_t)(M + 1) * 8));
+    TRY(launch_bucket_sort(c->qidx.as<int64_t>(), s.N, M, c->part_order.as<int32_t>(), c->part_ws.p, c->stream));
+    // launch_bucket_sort's workspace: [blk | count (M u32) | seg_start (M + 1 u32) | ...]
+    const int64_t nbh = (s.N + 2047) / 2048;
+    const uint32_t *seg_start = reinterpret_cast<const uint32_t *>(c->part_ws.as<char>() + align_up((size_t)nbh * M * 4) +
+                                                                  align_up((size_t)M * 4));
+    hipLaunchKernelGGL(seg_counts_kernel, dim3(grid1d(M)), dim3(256), 0, c->stream, seg_start, M, s.N, c->part_counts.as<int64_t>());
+    TRY(launch_status("seg_counts_kernel"));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(counts_host, c->part_counts.p, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
+    if (idx_host) DBGSOM_HIP_CHECK(hipMemcpyAsync(idx_host, c->qidx.p, (size_t)s.N * 8, hipMemcpyDeviceToHost, c->stream));
+    TRY(sync(c));
+    c->partM = M;
+    c->part_valid = true;
+    return DBGSOM_OK;
+}
+
+int dbgsom_ctx_subset_create(dbgsom_ctx *c, int64_t neuron, dbgsom_ctx **child_out) {
+    CTX_CHECK(c);
+    TRY(loaded(c, __func__));
+    DBGSOM_REQUIRE(child_out, "null pointer");
+    *child_out = nullptr;
+    if (!c->part_valid) { set_error("dbgsom_ctx_subset_create: call dbgsom_ctx_partition first"); return DBGSOM_ESTATE; }
+    DBGSOM_REQUIRE(neuron >= 0 && neuron < c->partM, "neuron out of range");
+    Samples &s = c->xs;
+    const int64_t nbh = (s.N + 2047) / 2048;
+    const uint32_t *seg_start = reinterpret_cast<const uint32_t *>(c->part_ws.as<char>() + align_up((size_t)nbh * c->partM * 4) +
+                                                                  align_up((size_t)c->partM * 4));
+    uint32_t seg[2] = {0, 0};
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(&seg[0], seg_start + neuron, 4, hipMemcpyDeviceToHost, c->stream));
+    if (neuron + 1 < c->partM)
+        DBGSOM_HIP_CHECK(hipMemcpyAsync(&seg[1], seg_start + neuron + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(sync(c));
+    if (neuron + 1 >= c->partM) seg[1] = (uint32_t)s.N;
+    const int64_t first = seg[0], n = (int64_t)seg[1] - (int64_t)seg[0];
+    if (n < 1) { set_error("dbgsom_ctx_subset_create: neuron %lld has no samples", (long long)neuron); return DBGSOM_EINVAL; }
+    dbgsom_ctx *k = nullptr;
+    TRY(dbgsom_ctx_create(c->device, &k));
+    k->algorithm = c->algorithm; k->sweep_planes = c->sweep_planes; k->seed_stride = c->seed_stride;
+    k->filter_min_query_rows = c->filter_min_query_rows; k->max_mean_candidates = c->max_mean_candidates;
+    k->allreduce = nullptr;  // a child map is fitted on this rank's rows alone
+    Samples &t = k->xs;
+    int rc = DBGSOM_OK;
+    do {
+        const size_t es = dtype_size(s.dtype);
+        if ((rc = t.own.reserve((size_t)n * s.dp * es))) break;
+        t.N = n; t.d = s.d; t.dp = s.dp; t.dtype = s.dtype; t.X = t.own.p;
+        const int32_t *order = c->part_order.as<int32_t>();
+        // the gather runs on the parent's stream (it reads the parent's buffers), then both are idle
+        if (s.dtype == DBGSOM_F32)
+            hipLaunchKernelGGL(gather_rows_kernel<float>, dim3((unsigned)n), dim3(256), 0, c->stream, (const float *)s.X, s.dp, order, first, n, s.dp, (float *)t.own.p);
+        else if (s.dtype == DBGSOM_F64)
+            hipLaunchKernelGGL(gather_rows_kernel<double>, dim3((unsigned)n), dim3(256), 0, c->stream, (const double *)s.X, s.dp, order, first, n, s.dp, (double *)t.own.p);
+        else
+            hipLaunchKernelGGL(gather_rows_kernel<uint16_t>, dim3((unsigned)n), dim3(256), 0, c->stream, (const uint16_t *)s.X, s.dp, order, first, n, s.dp, (uint16_t *)t.own.p);
+        if ((rc = launch_status("gather_rows_kernel"))) break;
+        if (c->has_labels) {
+            if ((rc = k->y.reserve((size_t)n * 4))) break;
+            hipLaunchKernelGGL(gather_i32_kernel, dim3(grid1d(n)), dim3(256), 0, c->stream, c->y.as<int32_t>(), order, first, n, k->y.as<int32_t>());
+            if ((rc = launch_status("gather_i32_kernel"))) break;
+            k->has_labels = true;
+        }
+        if ((rc = sync(c))) break;
+        if ((rc = finish_samples(k, t, false))) break;
+        rc = sync(k);
+    } while (0);
+    if (rc != DBGSOM_OK) { (void)hipStreamSynchronize(c->stream); dbgsom_ctx_destroy(k); return rc; }
+    *child_out = k;
+    return DBGSOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// diagnostics
+// ------------------------------------------------------------------------------------------
+int dbgsom_ctx_epoch_info(dbgsom_ctx *c, double *info8) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(info8, "null pointer");
+    info8[0] = c->last_filtered ? 1.0 : 0.0;
+    info8[1] = c->last_mean;
+    info8[2] = c->last_filtered ? (double)c->planes_used : 0.0;
+    info8[3] = c->last_hinted ? 1.0 : 0.0;
+    info8[4] = (double)c->filter_backoff;
+    info8[5] = (double)c->plane_hold;
+    info8[6] = 0.0;
+    info8[7] = 0.0;
+    return DBGSOM_OK;
+}
+
+int dbgsom_ctx_filter_counts(dbgsom_ctx *c, uint32_t *counts_host, int64_t n) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(counts_host, "null pointer");
+    if (!c->last_filter_ws) { set_error("dbgsom_ctx_filter_counts: no filtered search has run"); return DBGSOM_ESTATE; }
+    return dbgsom_bmu_filtered_counts(c->last_filter_ws, c->last_filter_N, c->last_filter_d, c->last_filter_M, counts_host, n,
+                                      c->stream);
+}
+
+int dbgsom_ctx_phase_ms(dbgsom_ctx *c, double *ms8) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(ms8, "null pointer");
+    if (!c->timing || !c->ev_valid) { set_error("dbgsom_ctx_phase_ms: no timed epoch (set option \"timing\")"); return DBGSOM_ESTATE; }
+    for (int k = 0; k < 3; ++k) {
+        float ms = 0.f;
+        DBGSOM_HIP_CHECK(hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]));
+        ms8[k] = ms;
+    }
+    for (int k = 0; k < 5; ++k) ms8[3 + k] = c->filter_ms_valid ? c->filter_ms[k] : 0.0;
+    return DBGSOM_OK;
+}
+
+}  // extern "C"

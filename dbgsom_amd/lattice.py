@@ -39,6 +39,7 @@ class GrowingLattice:
         self.epoch_created = np.zeros(4, dtype=np.int64)
         self._index = {n: i for i, n in enumerate(corners)}
         self._hops = None
+        self._overwritten = []  # rows of already occupied positions a growth step rewrote
 
     # -- views ----------------------------------------------------------------------------------
     @property
@@ -91,6 +92,16 @@ class GrowingLattice:
             for nb in rim:
                 err[idx[nb]] += 0.5 * e / len(rim)
             err[idx[node]] /= 2
+
+    def will_grow(self, threshold: float) -> bool:
+        """Whether `grow` would insert anything: its first candidate decides (it stops at the
+        first one that is interior or below the threshold)."""
+        i = int(np.argsort(-self.error)[0])
+        return bool(self.error[i] > threshold and self.graph.degree(self.nodes[i]) < 4)
+
+    def pop_overwritten(self):
+        rows, self._overwritten = sorted(set(self._overwritten)), []
+        return rows
 
     def grow(self, threshold: float, epoch: int) -> int:
         """Insert neurons next to boundary neurons whose error exceeds the threshold, largest
@@ -171,6 +182,7 @@ class GrowingLattice:
         if pos in self._index:  # the reference overwrites the attributes of an occupied position
             i = self._index[pos]
             self.W[i] = w
+            self._overwritten.append(i)
             self.error[i] = 0.0
             self.epoch_created[i] = epoch
         else:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DBGSOM_ABI_VERSION 1
+#define DBGSOM_ABI_VERSION 2
 
 /* sample storage types (the reference accepts float64 and float32 input: SomVQ.py:121-124) */
 #define DBGSOM_F32 0
@@ -46,6 +46,7 @@ extern "C" {
 #define DBGSOM_ENOMEM (-3)   /* workspace too small / allocation failed */
 #define DBGSOM_ESTATE (-4)   /* context used out of order (e.g. epoch before load) */
 #define DBGSOM_ERANGE (-5)   /* a winner index outside [0, M) was met */
+#define DBGSOM_ECALLBACK (-6) /* the caller's all-reduce callback reported a failure */
 
 /* prototype-count limit of the accumulate step (per-block LDS histogram) */
 #define DBGSOM_MAX_PROTOTYPES 16000
@@ -195,23 +196,86 @@ int dbgsom_class_histogram(const int64_t *idx_dev, const int32_t *y_dev, int64_t
 
 /* ------------------------------------------------------------------------------------------
  * Context-level entry points (host pointers; the library owns the device memory).
- * This is the seam a NumPy caller such as the reference binds with ctypes: X is uploaded once
- * and stays resident in HBM across epochs; every result is written into caller-allocated,
- * C-contiguous host arrays; no host pointer is retained after a call returns.
+ * This is the seam a NumPy caller such as the reference binds with ctypes, and it is THE PRODUCT:
+ * the estimators of dbgsom_amd are thin callers of it.  X is uploaded once and stays resident in
+ * HBM across epochs; every result is written into caller-allocated, C-contiguous host arrays; no
+ * host pointer is retained after a call returns.  Behind it, invisible to the caller: zero-padding
+ * of the rows to a multiple of 16 features (changes no fma chain), bfloat16 storage, the cached
+ * int8 digit planes, the choice between the all-pairs and the filtered search (always the same
+ * results), previous winners as seeds, device-resident prototypes between epochs.
+ * All calls are blocking; one host thread per context.
  * ------------------------------------------------------------------------------------------ */
 typedef struct dbgsom_ctx dbgsom_ctx;
+
+/* BMU search of a context -- every choice gives IDENTICAL results (option "algorithm") */
+#define DBGSOM_ALG_AUTO 0          /* FILTERED_HINT + back-off to EXACT while the candidate lists are long */
+#define DBGSOM_ALG_EXACT 1         /* all-pairs float64 MFMA search */
+#define DBGSOM_ALG_FILTERED 2      /* stateless: int8 seed pre-pass -> int8 candidate sweep -> exact float64 on candidates */
+#define DBGSOM_ALG_FILTERED_HINT 3 /* the same with the previous epoch's winners as seeds when there are any */
+
+/* flags of dbgsom_ctx_epoch */
+#define DBGSOM_EPOCH_FROZEN 1 /* the resident prototypes stay what they are (bench: same map every step) */
 
 int dbgsom_ctx_create(int device, dbgsom_ctx **out);
 int dbgsom_ctx_destroy(dbgsom_ctx *ctx);
 
-/* Upload the training samples once (BaseSom.fit's `X`, BaseSom.py:88-114). */
-int dbgsom_ctx_load(dbgsom_ctx *ctx, const void *X_host, int x_dtype, int64_t N, int64_t d);
+/* Integer options by name.  Settable: "algorithm" (DBGSOM_ALG_*), "sweep_planes" (0 adaptive,
+ * 1..3 fixed digit planes of the candidate sweep), "seed_stride" (0 = library default),
+ * "timing" (1: HIP events around the phases of an epoch and the stages of the filter),
+ * "filter_min_query_rows", "max_mean_candidates", "graph" (1: replay frozen / resident epochs from
+ * a HIP graph).  Readable besides those: "n_samples", "features", "padded_features", "prototypes",
+ * "planes_cached", "planes_used", "hint_valid", "filter_backoff", "plane_hold". */
+int dbgsom_ctx_set_option(dbgsom_ctx *ctx, const char *name, int64_t value);
+int dbgsom_ctx_get_option(dbgsom_ctx *ctx, const char *name, int64_t *value);
+/* the HIP stream (hipStream_t) every call of this context enqueues its work on */
+int dbgsom_ctx_stream(dbgsom_ctx *ctx, void **stream);
+
+/* Upload the training samples once (BaseSom.fit's `X`, BaseSom.py:88-114).  x_dtype: what X_host
+ * holds; storage: what stays in HBM -- the same, or DBGSOM_BF16 for float32 input rounded to
+ * nearest-even bfloat16 on the device (all arithmetic stays float64 on the exactly widened values;
+ * an extension, the reference has no bfloat16). */
+int dbgsom_ctx_load(dbgsom_ctx *ctx, const void *X_host, int x_dtype, int64_t N, int64_t d,
+                    int storage);
+/* Adopt samples that already live in HBM on the context's device (rows of ldx elements).  Borrowed
+ * without a copy when ldx is a multiple of 16 features that covers d and the rows are 16-byte
+ * aligned with zeros behind column d; copied (padded) otherwise.  The caller keeps the memory alive
+ * and unchanged until another load or dbgsom_ctx_destroy, and has finished writing it. */
+int dbgsom_ctx_load_device(dbgsom_ctx *ctx, const void *X_dev, int x_dtype, int64_t N, int64_t d,
+                           int64_t ldx);
+/* rows of the resident samples, widened to float64 (the four start prototypes of
+ * BaseSom._create_som BaseSom.py:419-444 without a host copy of X) */
+int dbgsom_ctx_read_samples(dbgsom_ctx *ctx, const int64_t *rows_host, int64_t n, double *out_host);
+/* integer class labels of the resident rows (entropy criterion BaseSom.py:547-551) */
+int dbgsom_ctx_set_labels(dbgsom_ctx *ctx, const int32_t *y_host, int64_t N);
 
 /* Lattice hop distances, M x M float64 as nx.floyd_warshall_numpy returns them
  * (BaseSom.py:367,401).  Call again whenever neurons were added. */
 int dbgsom_ctx_set_topology(dbgsom_ctx *ctx, const double *hop_host, int64_t M);
 
-/* _get_winning_neurons on the resident samples.  BaseSom.py:446-464. */
+/* Sample-sharded runs (one context per GPU / process): `fn` is called once per epoch, between the
+ * per-neuron sums and the smoothing, with the fused [S | K | a | E | status] buffer in HBM
+ * (count float64 values) and must leave the element-wise SUM over all ranks in it, ordered on
+ * `stream` (RCCL: ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, stream)).  The small
+ * reductions (QE, TE, node statistics, class histogram) go through it too.  NULL = single rank.
+ * Returns 0 on success; anything else makes the call fail with DBGSOM_ECALLBACK. */
+typedef int (*dbgsom_allreduce_fn)(void *user, double *buf_dev, int64_t count, void *stream);
+int dbgsom_ctx_set_allreduce(dbgsom_ctx *ctx, dbgsom_allreduce_fn fn, void *user);
+
+/* The prototypes resident in HBM (M x d float64; `weights_` of the reference).
+ *   set_weights   upload all of them
+ *   get_weights   which = 0: the resident ones (what an epoch with W_host = NULL consumes);
+ *                 which = 1: the other buffer -- after an epoch, the prototypes it consumed (the
+ *                 `weights_` snapshot of the reference, quirk Q3); after a FROZEN epoch, its output
+ *   read_weight_rows / write_weight_rows: single rows (growth step BaseSom.py:588-861: the
+ *                 extrapolated rows are O(d) each); writing at row0 == M appends (M grows) */
+int dbgsom_ctx_set_weights(dbgsom_ctx *ctx, const double *W_host, int64_t M);
+int dbgsom_ctx_get_weights(dbgsom_ctx *ctx, int which, double *W_host, int64_t M);
+int dbgsom_ctx_read_weight_rows(dbgsom_ctx *ctx, int which, const int64_t *rows_host, int64_t n,
+                                double *out_host);
+int dbgsom_ctx_write_weight_rows(dbgsom_ctx *ctx, int64_t row0, int64_t n, const double *rows_host);
+
+/* _get_winning_neurons on the resident samples.  BaseSom.py:446-464.  W_host = NULL: the resident
+ * prototypes.  k = 1 goes through the filtered search where it pays. */
 int dbgsom_ctx_bmu(dbgsom_ctx *ctx, const double *W_host, int64_t M, int k, int round_f32,
                    int64_t *idx_host, double *dist_host);
 
@@ -220,14 +284,72 @@ int dbgsom_ctx_bmu_query(dbgsom_ctx *ctx, const void *Xq_host, int x_dtype, int6
                          int64_t d, const double *W_host, int64_t M, int k, int round_f32,
                          int64_t *idx_host, double *dist_host);
 
+/* _calculate_exp_similarity on host values (BaseSom.py:533-538) */
+int dbgsom_ctx_exp_similarity(dbgsom_ctx *ctx, const double *dist_host, int64_t n, double gamma,
+                              double *kw_host);
+
 /* One pass of the body of BaseSom._grow_som (BaseSom.py:403-407):
- * BMU -> sample kernel -> weighted sums -> smoothing -> convergence norm -> per-neuron error.
- * Outputs (host): W_new M x d, change_total[1], errors[M], activations[M];
- * idx_host / dist_host (N each) may be NULL when the caller does not need the assignments. */
+ * BMU -> sample kernel -> weighted sums -> [all-reduce] -> smoothing -> convergence norm ->
+ * per-neuron error.
+ *   W_host     M x d prototypes to start from, or NULL = the resident ones
+ *   W_new_host M x d, or NULL: the new prototypes only stay in HBM (they become the resident ones
+ *              unless DBGSOM_EPOCH_FROZEN is set)
+ * Outputs (host): change_total[1], errors[M], activations[M]; idx_host / dist_host (N each) may be
+ * NULL when the caller does not need the assignments. */
 int dbgsom_ctx_epoch(dbgsom_ctx *ctx, const double *W_host, int64_t M, int round_f32,
-                     double gamma, double sigma, int layout, double *W_new_host,
+                     double gamma, double sigma, int layout, int flags, double *W_new_host,
                      double *change_total_host, double *errors_host, double *activations_host,
                      int64_t *idx_host, double *dist_host);
+
+/* _update_weights + _write_accumulative_error with the caller's own winners / sample weights /
+ * distances (N each, host): BaseSom.py:470-523, 541-561. */
+int dbgsom_ctx_update(dbgsom_ctx *ctx, const double *W_host, int64_t M, const int64_t *idx_host,
+                      const double *kw_host, const double *dist_host, double sigma, int layout,
+                      double *W_new_host, double *change_total_host, double *errors_host,
+                      double *activations_host);
+
+/* Seeds of the next filtered search: N winners (any indices < M keep the result exact). */
+int dbgsom_ctx_set_hint(dbgsom_ctx *ctx, const int64_t *idx_host, int64_t M);
+
+/* the last epoch's reduced sums [S (M x d) | K | a | E] (diagnostics / tests) */
+int dbgsom_ctx_read_sums(dbgsom_ctx *ctx, double *sums_host, int64_t M);
+
+/* ---- reductions around the path on the resident samples (SURVEY 8 f-1 .. f-3) ------------------- */
+/* dbgsom_column_sums on the resident samples: out / mean hold d elements of X's dtype */
+int dbgsom_ctx_column_sums(dbgsom_ctx *ctx, const void *mean_host, void *out_host);
+/* out2 = [sum of BMU distances, number of samples] over all ranks (BaseSom.py:904-922) */
+int dbgsom_ctx_quantization_error(dbgsom_ctx *ctx, const double *W_host, int64_t M, int round_f32,
+                                  double *out2_host);
+/* samples whose two BMUs are further than 1.5 apart on the lattice, over all ranks
+ * (BaseSom.py:924-953); xy: M x 2 int32 */
+int dbgsom_ctx_topographic_count(dbgsom_ctx *ctx, const double *W_host, int64_t M, int round_f32,
+                                 const int32_t *xy_host, double *count_host);
+/* hit counts and density sums per neuron over all ranks (BaseSom.py:181-211) */
+int dbgsom_ctx_node_statistics(dbgsom_ctx *ctx, const double *W_host, int64_t M, int round_f32,
+                               double sigma, double *hits_host, double *density_host);
+/* hist[j, c] over all ranks; idx_host = NULL: the winners of the last epoch (still in HBM) */
+int dbgsom_ctx_class_histogram(dbgsom_ctx *ctx, const int64_t *idx_host, int64_t n_classes,
+                               int64_t M, int64_t *hist_host);
+
+/* ---- vertical growth on Voronoi subsets (BaseSom.py:157-179) ------------------------------------ */
+/* BMU of every resident sample under W (NULL = resident prototypes) + stable bucket order;
+ * counts_host[M] = samples per neuron on this rank; idx_host (N, may be NULL) = the winners. */
+int dbgsom_ctx_partition(dbgsom_ctx *ctx, const double *W_host, int64_t M, int round_f32,
+                         int64_t *counts_host, int64_t *idx_host);
+/* a new context whose resident samples are the rows of neuron j's Voronoi set (sample order kept),
+ * gathered on the device; labels follow when the parent has them */
+int dbgsom_ctx_subset_create(dbgsom_ctx *ctx, int64_t neuron, dbgsom_ctx **child);
+
+/* ---- diagnostics ----------------------------------------------------------------------------- */
+/* info8 = [filtered search ran (0/1), mean candidate-list length, digit planes used, seeds were
+ *          previous winners (0/1), back-off epochs left, plane-policy hold, launches replayed from
+ *          a graph (0/1), reserved] of the last epoch */
+int dbgsom_ctx_epoch_info(dbgsom_ctx *ctx, double *info8);
+/* candidate-list length per 128-sample workgroup of the last filtered search (n = ceil(N/128)) */
+int dbgsom_ctx_filter_counts(dbgsom_ctx *ctx, uint32_t *counts_host, int64_t n);
+/* ms8 = [bmu, accumulate, smooth, slice W + tables, seed pre-pass, bucket sort, candidate sweep,
+ *        exact search on candidates] of the last epoch (option "timing" = 1) */
+int dbgsom_ctx_phase_ms(dbgsom_ctx *ctx, double *ms8);
 
 #ifdef __cplusplus
 }

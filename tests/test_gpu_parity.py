@@ -204,21 +204,23 @@ def test_determinism_bitwise(hip):
     assert np.array_equal(r1.errors, r2.errors) and r1.change_total == r2.change_total
 
 
-def test_ctx_api_numpy_only(o):
-    """The context-level ABI a NumPy caller (the reference) would bind: host pointers only."""
+@pytest.mark.parametrize("N,d,rows,cols", [(3000, 24, 4, 5), (9000, 50, 12, 13), (7000, 100, 16, 17)])
+def test_ctx_api_numpy_only(o, N, d, rows, cols):
+    """The context-level ABI a NumPy caller (the reference) would bind: host pointers only, no
+    torch.  The larger maps (M >= 129) go through the filtered search behind the same calls, the
+    feature counts are not multiples of 16 (padding happens behind the ABI too)."""
     from dbgsom_amd import _native as nat
 
     lib = nat.load()
     rng = np.random.default_rng(1)
-    N, d, rows, cols = 3000, 24, 4, 5
     M = rows * cols
-    X = rng.normal(size=(N, d)).astype(np.float32)
+    X = (rng.normal(size=(N, d)) + 3 * rng.integers(0, 5, size=(N, 1))).astype(np.float32)
     W = X[rng.choice(N, M, replace=False)].astype(np.float64)
     hop = gi.lattice_hops(rows, cols)
     ctx = ctypes.c_void_p()
     nat.call("dbgsom_ctx_create", 0, ctypes.byref(ctx))
     try:
-        nat.call("dbgsom_ctx_load", ctx, X.ctypes.data, nat.F32, N, d)
+        nat.call("dbgsom_ctx_load", ctx, X.ctypes.data, nat.F32, N, d, nat.F32)
         nat.call("dbgsom_ctx_set_topology", ctx, hop.ctypes.data, M)
         idx = np.empty((N, 2), np.int64)
         dist = np.empty((N, 2), np.float64)
@@ -228,14 +230,31 @@ def test_ctx_api_numpy_only(o):
         Wn = np.empty((M, d)); chg = np.empty(1); E = np.empty(M); a = np.empty(M)
         i1 = np.empty(N, np.int64); d1 = np.empty(N)
         gamma = float(np.var(X, axis=0).sum() ** -1)
-        nat.call("dbgsom_ctx_epoch", ctx, W.ctypes.data, M, 0, gamma, 0.9, nat.CENTRES_COMPACT,
+        nat.call("dbgsom_ctx_epoch", ctx, W.ctypes.data, M, 0, gamma, 0.9, nat.CENTRES_COMPACT, 0,
                  Wn.ctypes.data, chg.ctypes.data, E.ctypes.data, a.ctypes.data, i1.ctypes.data,
                  d1.ctypes.data)
+        info = (ctypes.c_double * 8)()
+        nat.call("dbgsom_ctx_epoch_info", ctx, info)
+        assert bool(info[0]) == (M >= 129)          # the filtered search ran behind the ABI
         oo = o.epoch(X, W, hop, 0.9, np.var(X, axis=0).sum(), "compact", "chain")
         assert np.array_equal(i1, oo.winners) and np.array_equal(d1, oo.distances)
         np.testing.assert_allclose(Wn, oo.new_weights, rtol=1e-11, atol=1e-13)
         np.testing.assert_allclose(E, oo.errors, rtol=1e-12)
         assert np.array_equal(a, oo.activations)
+        # the next epoch from the prototypes the first one left in HBM (W_host = NULL), seeded by
+        # its winners; new prototypes stay in HBM too (W_new_host = NULL) and are fetched after
+        nat.call("dbgsom_ctx_epoch", ctx, None, M, 0, gamma, 0.8, nat.CENTRES_COMPACT, 0, None,
+                 chg.ctypes.data, E.ctypes.data, a.ctypes.data, i1.ctypes.data, d1.ctypes.data)
+        nat.call("dbgsom_ctx_epoch_info", ctx, info)
+        assert bool(info[3]) == (M >= 129)          # previous winners were the seeds
+        o2 = o.epoch(X, oo.new_weights, hop, 0.8, np.var(X, axis=0).sum(), "compact", "chain")
+        W2 = np.empty((M, d))
+        nat.call("dbgsom_ctx_get_weights", ctx, 0, W2.ctypes.data, M)
+        Wprev = np.empty((M, d))
+        nat.call("dbgsom_ctx_get_weights", ctx, 1, Wprev.ctypes.data, M)
+        assert np.array_equal(Wprev, Wn)            # what the second epoch consumed
+        np.testing.assert_allclose(W2, o2.new_weights, rtol=1e-9, atol=1e-12)
+        assert np.array_equal(a, o2.activations)
         Xq = rng.normal(size=(50, d))
         iq = np.empty((50, 1), np.int64); dq = np.empty((50, 1))
         nat.call("dbgsom_ctx_bmu_query", ctx, Xq.ctypes.data, nat.F64, 50, d, W.ctypes.data, M, 1,
@@ -245,11 +264,58 @@ def test_ctx_api_numpy_only(o):
         # error behaviour: status codes + message, nothing thrown across the ABI
         rc = lib.dbgsom_ctx_bmu(ctx, W.ctypes.data, M, 3, 0, idx.ctypes.data, dist.ctypes.data)
         assert rc == -1 and b"bad arguments" in lib.dbgsom_last_error()
-        rc = lib.dbgsom_ctx_epoch(ctx, W.ctypes.data, M - 1, 0, gamma, 0.9, 0, Wn.ctypes.data,
+        rc = lib.dbgsom_ctx_epoch(ctx, W.ctypes.data, M - 1, 0, gamma, 0.9, 0, 0, Wn.ctypes.data,
                                   chg.ctypes.data, E.ctypes.data, a.ctypes.data, None, None)
         assert rc == -4
     finally:
         nat.call("dbgsom_ctx_destroy", ctx)
+
+
+def test_ctx_api_bf16_storage_and_allreduce_callback(o):
+    """bfloat16 storage behind dbgsom_ctx_load, and the all-reduce seam: a callback that leaves
+    the buffer alone (one rank) is called once per epoch with M * (d_padded + 3) + 1 values."""
+    import torch
+
+    from dbgsom_amd import _native as nat
+
+    rng = np.random.default_rng(4)
+    N, d, rows, cols = 5000, 72, 12, 12
+    M = rows * cols
+    X = (rng.normal(size=(N, d)) + 2 * rng.integers(0, 6, size=(N, 1))).astype(np.float32)
+    Xr = _bf16_round(X)
+    W = Xr[rng.choice(N, M, replace=False)].astype(np.float64)
+    hop = gi.lattice_hops(rows, cols)
+    seen = []
+
+    def cb(_user, ptr, count, stream):
+        seen.append(int(count))
+        return 0
+
+    fn = nat.ALLREDUCE_FN(cb)
+    ctx = ctypes.c_void_p()
+    nat.call("dbgsom_ctx_create", 0, ctypes.byref(ctx))
+    try:
+        nat.call("dbgsom_ctx_load", ctx, X.ctypes.data, nat.F32, N, d, nat.BF16)
+        nat.call("dbgsom_ctx_set_topology", ctx, hop.ctypes.data, M)
+        nat.call("dbgsom_ctx_set_allreduce", ctx, fn, None)
+        Wn = np.empty((M, d)); chg = np.empty(1); E = np.empty(M); a = np.empty(M)
+        i1 = np.empty(N, np.int64); d1 = np.empty(N)
+        nat.call("dbgsom_ctx_epoch", ctx, W.ctypes.data, M, 0, 1e-3, 1.1, nat.CENTRES_COMPACT, 0,
+                 Wn.ctypes.data, chg.ctypes.data, E.ctypes.data, a.ctypes.data, i1.ctypes.data,
+                 d1.ctypes.data)
+        assert seen == [M * (80 + 3) + 1]
+        oo = o.epoch(Xr, W, hop, 1.1, np.float64(1e3), "compact", "chain")
+        assert np.array_equal(i1, oo.winners) and np.array_equal(d1, oo.distances)
+        np.testing.assert_allclose(Wn, oo.new_weights, rtol=1e-11, atol=1e-13)
+        # a failing callback comes back as a status code
+        bad = nat.ALLREDUCE_FN(lambda u, p, c, s: 7)
+        nat.call("dbgsom_ctx_set_allreduce", ctx, bad, None)
+        rc = nat.load().dbgsom_ctx_epoch(ctx, W.ctypes.data, M, 0, 1e-3, 1.1, 0, 0, Wn.ctypes.data,
+                                         chg.ctypes.data, E.ctypes.data, a.ctypes.data, None, None)
+        assert rc == -6
+    finally:
+        nat.call("dbgsom_ctx_destroy", ctx)
+    del torch
 
 
 def test_full_size_properties(hip, o):
@@ -282,10 +348,9 @@ def test_full_size_properties(hip, o):
     assert res.activations.sum() == N
     np.testing.assert_allclose(res.errors.sum(), dist.sum(), rtol=1e-10)
     kw = 1 - np.sqrt(1 - np.exp(-gamma * dist ** 2))
-    sums, _, _ = hip._local_sums(W, gamma, False)
-    S = sums[: M * d].view(M, d)
+    S = hip.read_sums(M)[: M * d].reshape(M, d)
     col_ref = (torch.from_numpy(kw).cuda()[None, :] @ X.double()).view(-1)
-    np.testing.assert_allclose(S.sum(dim=0).cpu().numpy(), col_ref.cpu().numpy(), rtol=1e-9)
+    np.testing.assert_allclose(S.sum(axis=0), col_ref.cpu().numpy(), rtol=1e-9)
     # (4) permutation equivariance of the BMU step
     perm = torch.randperm(N, device="cuda", generator=gen)
     hip.load_device(X[perm].contiguous())
@@ -384,7 +449,7 @@ def test_bf16_samples_filtered_search_is_identical_to_exact(o):
     fi = HipBackend(algorithm="filtered").load(X, storage="bf16")
     re_ = ex.epoch(W, hop, 3.0, 1e-3, "compact", True)
     rf = fi.epoch(W, hop, 3.0, 1e-3, "compact", True)
-    assert fi._planes is not None and fi._X.dtype.is_floating_point and fi._X.element_size() == 2
+    assert fi.planes_cached and fi._x_np_dtype == "bf16"
     assert np.array_equal(re_.winners, rf.winners) and np.array_equal(re_.distances, rf.distances)
     assert np.array_equal(re_.new_weights, rf.new_weights)
     pick = np.random.default_rng(0).choice(N, 1500, replace=False)
@@ -425,7 +490,7 @@ def test_filtered_search_is_identical_to_exact(o, N, d, rows, cols):
         counts = filt.filter_counts()
         assert counts.min() >= 1 and counts.max() <= M
         sigma *= 0.6
-    assert filt._planes is not None and stateless._planes is not None
+    assert filt.planes_cached and stateless.planes_cached
     # oracle spot check of the last filtered epoch
     pick = np.random.default_rng(0).choice(N, 1500, replace=False)
     W_last_in = We if False else None  # (weights fed to the last epoch are not kept; check below)
@@ -447,7 +512,7 @@ def test_feature_counts_that_are_not_multiples_of_16_take_the_fast_paths_unchang
     W = X[np.random.default_rng(4).choice(N, M, replace=False)].astype(np.float64) + 0.001
     hop = gi.lattice_hops(rows, cols)
     be = HipBackend(algorithm=algo).load(X)
-    assert be._X.shape[1] % 16 == 0 and be._d == d
+    assert be.padded_features % 16 == 0 and be._d == d
     res = be.epoch(W, hop, 1.5, 1e-3, "compact", True)
     oo = o.epoch(X, W, hop, 1.5, np.float64(1e3), "compact", "chain")
     assert res.new_weights.shape == (M, d)
@@ -457,7 +522,8 @@ def test_feature_counts_that_are_not_multiples_of_16_take_the_fast_paths_unchang
     assert abs(res.change_total - oo.change_total) <= 1e-10 * max(1.0, abs(oo.change_total))
     # device-resident chaining hands out (M, d) views and takes them back
     r1 = be.epoch(W, hop, 1.5, 1e-3, "compact", False, keep_on_device=True)
-    assert tuple(r1.new_weights_dev.shape) == (M, d)
+    assert r1.new_weights is None and r1.new_weights_dev is not None
+    assert be.get_weights(0).shape == (M, d)
     r2 = be.epoch(r1.new_weights_dev, hop, 1.2, 1e-3, "compact", False)
     o2 = o.epoch(X, oo.new_weights, hop, 1.2, np.float64(1e3), "compact", "chain")
     np.testing.assert_allclose(r2.new_weights, o2.new_weights, rtol=1e-9, atol=1e-12)
@@ -482,7 +548,7 @@ def test_large_queries_take_the_filtered_search_and_agree_with_the_all_pairs_ker
     W = X[np.random.default_rng(3).choice(N, M, replace=False)].astype(np.float64) + 0.01
     auto = HipBackend(algorithm="auto").load(X[:5000])
     exact = HipBackend(algorithm="exact").load(X[:5000])
-    assert auto._query_filter_applies(N, d, M, X.dtype, 1) and not exact._query_filter_applies(N, d, M, X.dtype, 1)
+    assert auto.query_filter_applies(N, d, M, 1) and not exact.query_filter_applies(N, d, M, 1)
     da, ia = auto.bmu(W, 1, X)
     de, ie = exact.bmu(W, 1, X)
     assert np.array_equal(ia, ie) and np.array_equal(da, de)
@@ -492,7 +558,7 @@ def test_large_queries_take_the_filtered_search_and_agree_with_the_all_pairs_ker
     # resident samples, digit planes cached by the query itself
     big = HipBackend(algorithm="auto").load(X)
     db, ib = big.bmu(W, 1)
-    assert big._planes is not None and np.array_equal(ib, ie) and np.array_equal(db, de)
+    assert big.planes_cached and np.array_equal(ib, ie) and np.array_equal(db, de)
     d2, i2 = big.bmu(W, 2)          # k = 2 stays on the all-pairs kernel
     assert np.array_equal(i2[:, 0], ie)
 
@@ -501,7 +567,6 @@ def test_filtered_search_with_ties_and_bad_previous_winners(o):
     """Duplicated prototypes (exact ties -> lowest index) and deliberately wrong previous winners:
     the result must not depend on the quality of the hint."""
     from dbgsom_amd.backend import HipBackend
-    import torch
 
     rng = np.random.default_rng(5)
     N, d, M = 6000, 32, 300
@@ -517,9 +582,7 @@ def test_filtered_search_with_ties_and_bad_previous_winners(o):
     rd, ri = o.bmu_chain(X, W, 1)
     assert np.array_equal(r1.winners, ri) and np.array_equal(r1.distances, rd)
     # poison the hint: random previous winners (the bucket order must match them)
-    bad = torch.from_numpy(rng.integers(0, M, size=N)).to(be.device)
-    order = torch.argsort(bad, stable=True).to(torch.int32)
-    be._prev_idx, be._order = bad, order
+    be.set_hint(rng.integers(0, M, size=N), M)
     r2 = be.epoch(W, hop, 2.0, 0.01, "compact", True)
     assert np.array_equal(r2.winners, ri) and np.array_equal(r2.distances, rd)
 
@@ -588,7 +651,7 @@ def test_float64_samples_take_the_filtered_search(o, N, d, rows, cols):
     for e in range(2):
         rf = fi.epoch(W, hop, 2.0, 1e-3, "compact", True)
         re_ = ex.epoch(W, hop, 2.0, 1e-3, "compact", True)
-        assert fi._planes is not None
+        assert fi.planes_cached
         assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances)
         assert np.array_equal(rf.new_weights, re_.new_weights)
         W = re_.new_weights
@@ -663,8 +726,8 @@ def test_adaptive_digit_planes_settle_on_the_cheaper_sweep(o):
             assert np.array_equal(r.winners, q.winners) and np.array_equal(r.distances, q.distances)
         used = [entry[2] for entry in be.filter_log]
         means = {p: m for (_, m, p) in be.filter_log}
-        assert used[0] == 1 and used[-1] == used[-2] and be._plane_state["hold"] > 0, used   # settled
-        best = min(means, key=lambda p: be._plane_cost(p, means[p], M))
+        assert used[0] == 1 and used[-1] == used[-2] and be._get("plane_hold") > 0, used   # settled
+        best = min(means, key=lambda p: be.plane_cost(p, means[p], M))
         assert used[-1] == best, (used, means)
         if settle is None:
             assert used[-1] >= 2, (used, means)
