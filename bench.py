@@ -1,28 +1,36 @@
 #!/usr/bin/env python
 """Benchmark of the batch-SOM hot path on MI355X: samples/sec/epoch (BMU + update).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|c5|c4iso|c2nn]
+                    [--scaling strong|weak] [--via backend|ctx]
 
 One "step" = one epoch of the hot path (reference dbgsom/BaseSom.py:403-407: BMU search, sample
 kernel, per-neuron sums, [all-reduce], neighbourhood smoothing, convergence norm, per-neuron
 error) at the FROZEN map of SURVEY.md 8(d): full rows x cols lattice, prototypes = M rows of the
 samples, sigma = 0.2 sqrt(M), gamma = 1 / sum of variances, samples resident in HBM.  Every step
-starts from the same prototypes and computes everything again.
+starts from the same prototypes and computes everything again -- ONE call of the C ABI
+(`dbgsom_ctx_epoch`) per step.
 
 The headline uses the stateless filtered search (`algorithm="filtered"`: coarse int8-MFMA pre-pass
 -> int8 candidate sweep with a rigorous error bound -> exact float64 search on the candidates;
 results bit-identical to the all-pairs float64 search, nothing carried over between steps).  The
-same JSON line also carries the all-pairs exact search (`exact`) and a training-like secondary
-regime (`fine_phase`).
+same JSON line also carries the all-pairs exact search (`exact`), a training-like secondary
+regime (`fine_phase`) and, at N = 1, two weakly clustered data sets (`other_data`) that show how
+much of the headline is a property of the data.
 
-For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU, RCCL);
-samples are sharded by rows (each rank generates its own shard: weak scaling, per-GPU work
-fixed) and the only collective is the all-reduce of the [S|K|a|E] sums, once per epoch.
+`--via ctx` drives the same epoch with NumPy + ctypes only (no torch is imported): the seam a
+maintainer of the reference would bind.
+
+For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU, RCCL).
+BASELINE's metric is "N = 1e6 ... sample-sharded 1/2/4/8": the default `--scaling strong` keeps the
+total N of the workload and gives every rank N / G rows; `--scaling weak` gives every rank the
+whole N.  The only collective is the all-reduce of the [S|K|a|E] sums, once per epoch.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -35,23 +43,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (samples per GPU, features, lattice rows, cols, seed, BASELINE.json config)
-    "c4": (1_000_000, 784, 32, 32, 1004, "Synthetic N=1e6 d=784 fp32, M=1024 (32x32)"),
-    "c3": (1_000_000, 128, 45, 45, 1003, "Synthetic Gaussian blobs N=1e6 d=128 fp32, M=2025 (45x45)"),
-    "c2": (60_000, 784, 22, 23, 1002, "Fashion-MNIST stand-in 60k x 784 fp32, M=506 (22x23)"),
+    # name: (samples, features, lattice rows, cols, seed, data kind, BASELINE.json config)
+    "c4": (1_000_000, 784, 32, 32, 1004, "blobs", "Synthetic N=1e6 d=784 fp32, M=1024 (32x32)"),
+    "c3": (1_000_000, 128, 45, 45, 1003, "blobs", "Synthetic Gaussian blobs N=1e6 d=128 fp32, M=2025 (45x45)"),
+    "c2": (60_000, 784, 22, 23, 1002, "blobs", "Fashion-MNIST stand-in 60k x 784 fp32, M=506 (22x23)"),
     # one GPU's shard of BASELINE config 5 (N=4e6 over 8 GPUs), samples resident as bfloat16
-    "c5": (500_000, 2048, 64, 64, 1005, "Synthetic N=4e6/8 d=2048 bf16, M=4096 (64x64)"),
+    "c5": (500_000, 2048, 64, 64, 1005, "blobs", "Synthetic N=4e6/8 d=2048 bf16, M=4096 (64x64)"),
+    # weakly clustered data: where the filter has nothing to hold on to
+    "c4iso": (1_000_000, 784, 32, 32, 1014, "iso", "isotropic Gaussian N=1e6 d=784 fp32, M=1024 (32x32)"),
+    "c2nn": (60_000, 784, 22, 23, 1012, "nonneg",
+             "Fashion-MNIST stand-in, non-negative variant of SURVEY 8(d): clip(blobs, 0) scaled to "
+             "[0, 255] then standardised, 60k x 784 fp32, M=506"),
 }
 BF16_WORKLOADS = ("c5",)
 F64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 cycles (v_mfma_f64_16x16x4_f64)
 I8_MFMA_PEAK_TOPS = 5033.0   # 256 x 4 x 2.4 GHz x 65536 op / 32 cycles (v_mfma_i32_32x32x32_i8, dense)
-# HBM-side bytes of one full-sweep launch at C4 from the PMC passes committed under profiles/
-# (FETCH_SIZE x 2 per the gfx950 correction); not measurable inside this process.  Keyed by the
-# number of digit planes the sweep reads (1 -> sweep_i8_kernel<0,1,4>, 2 -> <0,2,2>, 3 -> <0,3,1>)
-SWEEP_TRAFFIC_C4_BYTES = {1: 1.99e9, 2: 7.90e9, 3: 2.42e10}
-SWEEP4_TRAFFIC_C4_BYTES = 4.14e9  # sweep4_i8_kernel (one product, 4-wavefront workgroups): plane 0 of X once per 256 prototypes
-SWEEP_KERNEL = {1: "sweep_i8_kernel<0,1,4>", 2: "sweep_i8_kernel<0,2,2>", 3: "sweep_i8_kernel<0,3,1>"}
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured achievable)
 SWEEP_PRODUCTS = {1: 1, 2: 3, 3: 6}   # int8 digit products kept per (sample, prototype, k)
+SWEEP_KERNEL = {1: "sweep4_i8_kernel<0,8>", 2: "sweep_i8_kernel<0,2,2>", 3: "sweep_i8_kernel<0,3,1>"}
+PHASES = ("bmu", "accumulate", "smooth", "slice_w", "prepass", "bucket_sort", "sweep",
+          "exact_on_candidates")
 
 
 def lattice_hops(rows, cols):
@@ -59,10 +70,39 @@ def lattice_hops(rows, cols):
     return (np.abs(ii[:, None] - ii[None]) + np.abs(jj[:, None] - jj[None])).astype(np.float64)
 
 
-def make_shard(torch, n, d, seed, device, rank=0):
-    """This rank's rows of the Gaussian-blob data set of SURVEY.md 8(d): 32 centres ~ N(0, 16 I)
-    (ONE set for the whole data set, from `seed`), unit noise; the rows come from the stream
-    `seed + rank`.  Generated in HBM."""
+def source_hash():
+    """sha256 over the kernel sources: the key under which profiles/pmc_traffic.json holds the
+    HBM bytes per launch that a rocprofv3 --pmc pass of THIS build measured."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "dbgsom_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass of this very build, or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    entry = table.get(source_hash(), {}).get(workload, {})
+    for key, val in entry.items():
+        if key != "source" and kernel.startswith(key):
+            return float(val), entry.get("source")
+    return None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic data (SURVEY.md 8(d))
+# ---------------------------------------------------------------------------------------------
+def make_shard(torch, n, d, seed, device, rank=0, kind="blobs"):
+    """This rank's rows, generated in HBM.  blobs: 32 centres ~ N(0, 16 I) (ONE set for the whole
+    data set, from `seed`), unit noise; the rows come from the stream `seed + rank`.
+    iso: one isotropic Gaussian.  nonneg: clip(blobs, 0), scaled to [0, 255], standardised."""
     gen = torch.Generator(device=device).manual_seed(seed)
     centers = torch.randn(32, d, device=device, generator=gen) * 4.0
     if rank:  # rank 0 goes on with the stream that drew the centres
@@ -71,14 +111,41 @@ def make_shard(torch, n, d, seed, device, rank=0):
     step = 100_000
     for s in range(0, n, step):  # chunked: no N x d float64 temporaries
         m = min(step, n - s)
-        lab = torch.randint(0, 32, (m,), device=device, generator=gen)
-        X[s:s + m] = centers[lab] + torch.randn(m, d, device=device, generator=gen)
+        if kind == "iso":
+            X[s:s + m] = torch.randn(m, d, device=device, generator=gen)
+        else:
+            lab = torch.randint(0, 32, (m,), device=device, generator=gen)
+            X[s:s + m] = centers[lab] + torch.randn(m, d, device=device, generator=gen)
+    if kind == "nonneg":
+        X.clamp_(min=0)
+        X.mul_(255.0 / float(X.max()))
+        mean, std = X.mean(dim=0), X.std(dim=0)
+        X.sub_(mean).div_(std.clamp(min=1e-6))
     return X
 
 
-def cpu_baseline(workload, Xs, W, hop, sigma, gamma, n_full):
+def make_shard_numpy(n, d, seed, kind="blobs"):
+    """The same distributions from NumPy on the host (`--via ctx`: no torch anywhere)."""
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((32, d)).astype(np.float32) * 4.0
+    X = np.empty((n, d), dtype=np.float32)
+    step = 100_000
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        noise = rng.standard_normal((m, d), dtype=np.float32)
+        X[s:s + m] = noise if kind == "iso" else centers[rng.integers(0, 32, m)] + noise
+    return X
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (the oracle port of the reference path), rank 0 at N = 1 only
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline(Xs, W, hop, sigma, gamma, n_full):
     """The reference CPU path (oracle port: sklearn NearestNeighbors + NumPy) on a bounded row
-    sample, extrapolated to the full N: t = (t_bmu + t_acc) * N / Ns + t_smooth."""
+    sample, extrapolated to the full N: t = (t_bmu + t_acc) * N / Ns + t_smooth, with the smoothing
+    both ways SURVEY.md 8(d) asks for: (ii) matmul form -- the fair baseline behind `value` -- and
+    (i) the reference's own (M, M, d) broadcast (BaseSom.py:509-515), timed on a block of output
+    rows and scaled to M (its temporary is M x M x d float64: 6.6 GB at C4, 550 GB at C5)."""
     from oracle import som_oracle as o
 
     try:
@@ -87,7 +154,7 @@ def cpu_baseline(workload, Xs, W, hop, sigma, gamma, n_full):
         bmu, engine = o.bmu_sklearn, "sklearn NearestNeighbors.kneighbors"
     except ImportError:
         bmu, engine = o.bmu_blas, "NumPy dgemm expanded-L2"
-    M = W.shape[0]
+    M, d = W.shape
     # size the sample for ~15 s of CPU work: probe the BMU rate on 10k rows first
     tp = time.perf_counter()
     bmu(Xs[:10_000], W, 1)
@@ -101,10 +168,19 @@ def cpu_baseline(workload, Xs, W, hop, sigma, gamma, n_full):
     S, K, a, E = o.accumulate_numpy(Xs, win, kw, dist, M)
     t2 = time.perf_counter()
     C = o.voronoi_centers(S, K, a, "compact")
-    Wn = o.smooth_matmul(o.gaussian_neighborhood(hop, sigma), a, C)
+    h = o.gaussian_neighborhood(hop, sigma)
+    Wn = o.smooth_matmul(h, a, C)
     o.change_total(W, Wn)
     t3 = time.perf_counter()
+    # (i) reference-faithful broadcast on a row block sized for <= 1 GiB of temporary
+    rows_b = int(max(1, min(M, (1 << 30) // (M * d * 8))))
+    tb0 = time.perf_counter()
+    Wb = o.smooth_broadcast_rows(h, a, C, 0, rows_b)
+    t_block = time.perf_counter() - tb0
+    t_broadcast = t_block * (M / rows_b)
+    same = bool(np.allclose(Wb, Wn[:rows_b], rtol=1e-9, atol=1e-12, equal_nan=True))
     t_epoch = (t2 - t0) * (n_full / ns) + (t3 - t2)
+    t_epoch_ref = (t2 - t0) * (n_full / ns) + t_broadcast
     try:
         from threadpoolctl import threadpool_info
 
@@ -120,9 +196,171 @@ def cpu_baseline(workload, Xs, W, hop, sigma, gamma, n_full):
                    f"CSR-matmul sums; matmul smoothing), bmu {t1 - t0:.2f}s acc {t2 - t1:.2f}s "
                    f"smooth {t3 - t2:.2f}s, BLAS threads {blas_threads}; "
                    "extrapolated t=(bmu+acc)*N/Ns+smooth"),
+        "value_reference_faithful_smoothing": n_full / t_epoch_ref,
+        "smoothing_s": {"matmul": t3 - t2, "broadcast_MMd": t_broadcast,
+                        "broadcast_sample": f"{rows_b} of {M} output rows ({t_block:.2f}s, "
+                                            f"{rows_b * M * d * 8 / 2**30:.2f} GiB temporary), x M/rows; "
+                                            f"equal to the matmul form: {same}"},
     }
 
 
+# ---------------------------------------------------------------------------------------------
+# roofline entries
+# ---------------------------------------------------------------------------------------------
+def list_flops(counts, n, d):
+    """(useful, executed) float64 flops of the exact-on-candidates stage from the candidate-list
+    lengths: a 128-sample workgroup evaluates its list in steps of 16 / 32 / 48 prototypes
+    (classes <= 16, 17..32, > 32), every row of the workgroup against every listed prototype."""
+    counts = counts.astype(np.float64)
+    rows = np.full(counts.shape, 128.0)
+    if n % 128:
+        rows[-1] = n % 128
+    step = np.where(counts <= 16, 16.0, np.where(counts <= 32, 32.0, 48.0))
+    padded = np.ceil(counts / step) * step
+    return float((2.0 * rows * counts * d).sum()), float((2.0 * 128.0 * padded * d).sum())
+
+
+def rooflines(workload, n, d, M, xbytes, ph, planes, counts):
+    """One entry per dominant stage of the filtered epoch, each reproducible from profiles/:
+    achieved = ALGORITHMIC work of one launch / its HIP-event duration in this run."""
+    flops = 2.0 * n * M * d
+    out = []
+    if ph["sweep"] > 0:
+        ops = flops * SWEEP_PRODUCTS[planes]     # int8 multiply-adds x 2 on the d real features
+        ach = ops / (ph["sweep"] * 1e-3) / 1e12
+        kern = SWEEP_KERNEL[planes]
+        traffic, src = measured_traffic(workload, "sweep")
+        out.append({"stage": "candidate sweep", "kernel": kern, "bound": "mfma", "dtype": "i8",
+                    "achieved": ach, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                    "frac": ach / I8_MFMA_PEAK_TOPS, "kernel_ms": ph["sweep"],
+                    "digit_products": SWEEP_PRODUCTS[planes], "traffic": traffic,
+                    "traffic_source": src, "algorithmic_bytes": float(n) * d})
+    if ph["exact_on_candidates"] > 0 and counts is not None:
+        useful, padded = list_flops(counts, n, d)
+        t = ph["exact_on_candidates"] * 1e-3
+        traffic, src = measured_traffic(workload, "subset_exact")
+        out.append({"stage": "exact search on candidates", "kernel": "subset_exact_kernel (3 list-length classes)",
+                    "bound": "mfma", "dtype": "f64", "achieved": useful / t / 1e12,
+                    "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": useful / t / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                    "executed_TFLOPs": padded / t / 1e12,
+                    "executed_frac": padded / t / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                    "kernel_ms": ph["exact_on_candidates"], "traffic": traffic, "traffic_source": src,
+                    "algorithmic_bytes": float(n) * d * xbytes})
+    if ph["bmu"] > 0:
+        out.append({"stage": "whole BMU search", "kernel": "all stages of dbgsom_bmu_filtered", "bound": "mfma",
+                    "dtype": "f64-equivalent", "achieved": flops / (ph["bmu"] * 1e-3) / 1e12,
+                    "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (2 N M d of the search it replaces)",
+                    "frac": flops / (ph["bmu"] * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                    "kernel_ms": ph["bmu"], "traffic": None})
+    if ph["accumulate"] > 0:
+        gbps = n * d * xbytes / (ph["accumulate"] * 1e-3) / 1e9
+        traffic, src = measured_traffic(workload, "segsum")
+        out.append({"stage": "accumulate (sort + segmented sums)", "kernel": "segsum_kernel + sort / finalize",
+                    "bound": "hbm", "dtype": "f64 sums of " + ("bf16" if xbytes == 2 else "f32") + " rows",
+                    "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                    "kernel_ms": ph["accumulate"], "traffic": traffic, "traffic_source": src,
+                    "algorithmic_bytes": float(n) * d * xbytes})
+    return out
+
+
+def exact_roofline(n, d, M, bmu_ms):
+    ach = 2.0 * n * M * d / (bmu_ms * 1e-3) / 1e12
+    return {"stage": "all-pairs BMU search", "bound": "mfma", "kernel": "bmu_dma_kernel<float,1,4>",
+            "dtype": "f64", "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel_ms": bmu_ms}
+
+
+def count_stats(c):
+    return {"mean": float(c.mean()), "p90": float(np.percentile(c, 90)), "max": int(c.max())}
+
+
+# ---------------------------------------------------------------------------------------------
+# --via ctx: NumPy + ctypes only
+# ---------------------------------------------------------------------------------------------
+def run_via_ctx(args):
+    """The headline step through the raw context-level ABI: no torch, no HipBackend."""
+    from dbgsom_amd import _native as nat
+
+    n, d, rows, cols, seed, kind, cfg_name = WORKLOADS[args.workload]
+    if args.samples_per_gpu:
+        n = args.samples_per_gpu
+    M = rows * cols
+    t_gen = time.perf_counter()
+    X = make_shard_numpy(n, d, seed, kind)
+    t_gen = time.perf_counter() - t_gen
+    rng = np.random.default_rng(seed + 7)
+    W0 = X[rng.choice(n, M, replace=False)].astype(np.float64)
+    gamma = float(1.0 / np.var(X[:200_000].astype(np.float64), axis=0).sum())
+    hop = lattice_hops(rows, cols)
+    sigma = 0.2 * np.sqrt(M)
+    ctx = ctypes.c_void_p()
+    nat.call("dbgsom_ctx_create", 0, ctypes.byref(ctx))
+    out = {}
+    try:
+        t_up = time.perf_counter()
+        st = nat.BF16 if args.workload in BF16_WORKLOADS else nat.F32
+        nat.call("dbgsom_ctx_load", ctx, X.ctypes.data, nat.F32, n, d, st)
+        t_up = time.perf_counter() - t_up
+        nat.call("dbgsom_ctx_set_topology", ctx, hop.ctypes.data, M)
+        chg, E, a = np.empty(1), np.empty(M), np.empty(M)
+        Wn = {}
+        for algo in dict.fromkeys([args.algorithm, "exact"]):
+            nat.call("dbgsom_ctx_set_option", ctx, b"algorithm", nat.ALGORITHMS[algo])
+            nat.call("dbgsom_ctx_set_option", ctx, b"timing", 1)
+            nat.call("dbgsom_ctx_set_weights", ctx, W0.ctypes.data, M)
+
+            def step():
+                nat.call("dbgsom_ctx_epoch", ctx, None, M, 0, gamma, sigma, nat.CENTRES_COMPACT,
+                         nat.EPOCH_FROZEN, None, chg.ctypes.data, E.ctypes.data, a.ctypes.data, None, None)
+
+            for _ in range(args.warmup):
+                step()
+            ms = (ctypes.c_double * 8)()
+            acc = np.zeros(8)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            elapsed = time.perf_counter() - t0
+            for _ in range(3):   # phase times from three more (untimed) steps
+                step()
+                nat.call("dbgsom_ctx_phase_ms", ctx, ms)
+                acc += np.array(list(ms)) / 3
+            Wn[algo] = np.empty((M, d))
+            nat.call("dbgsom_ctx_get_weights", ctx, 1, Wn[algo].ctypes.data, M)
+            out[algo] = (elapsed, dict(zip(PHASES, acc.tolist())))
+    finally:
+        nat.call("dbgsom_ctx_destroy", ctx)
+    elapsed, ph = out[args.algorithm]
+    e_elapsed, e_ph = out["exact"]
+    line = {
+        "metric": "samples/sec/epoch (BMU+update)", "value": n * args.steps / elapsed,
+        "unit": "samples/s/epoch", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic (NumPy on the host)",
+        "config": {"workload": cfg_name, "samples": n, "features": d, "prototypes": M,
+                   "x_storage": "bf16" if args.workload in BF16_WORKLOADS else "f32",
+                   "map": "frozen (same prototypes every step)", "bmu_algorithm": args.algorithm,
+                   "via": "ctx: dbgsom_ctx_* through ctypes, NumPy host arrays only"},
+        "roofline": exact_roofline(n, d, M, e_ph["bmu"]) if args.algorithm == "exact" else
+        {"stage": "whole BMU search", "bound": "mfma", "dtype": "f64-equivalent",
+         "achieved": 2.0 * n * M * d / (ph["bmu"] * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TFLOPS,
+         "unit": "TFLOP/s (2 N M d of the search it replaces)",
+         "frac": 2.0 * n * M * d / (ph["bmu"] * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+         "kernel_ms": ph["bmu"]},
+        "phases_ms": ph,
+        "exact": {"value": n * args.steps / e_elapsed, "ms_per_step": e_elapsed / args.steps * 1e3,
+                  "prototypes_identical_to_headline": bool(np.array_equal(Wn["exact"], Wn[args.algorithm],
+                                                                           equal_nan=True))},
+        "host_s": {"generate": t_gen, "dbgsom_ctx_load (PCIe upload + norms)": t_up},
+        "torch_imported": "torch" in sys.modules,
+    }
+    print(json.dumps(line))
+
+
+# ---------------------------------------------------------------------------------------------
+# default path: HipBackend (thin over the same ABI) + torch.distributed for N > 1
+# ---------------------------------------------------------------------------------------------
 class Harness:
     def __init__(self, torch, td, args, local, world, grouped):
         self.torch, self.td, self.args = torch, td, args
@@ -143,93 +381,111 @@ class Harness:
     def timed_epochs(self, be, step_fn, warmup, steps):
         """W untimed steps, then exactly `steps` timed ones bracketed by barrier + synchronize;
         returns (max-over-ranks seconds, per-phase mean ms from HIP events on the launch stream)."""
-        be.kernel_events = None
+        be.phase_log = None
         for _ in range(warmup):
             step_fn()
-        be.kernel_events = []
+        be.phase_log = []
         self.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             step_fn()
         self.sync()
         elapsed = self.max_over_ranks(time.perf_counter() - t0)
-        ev, be.kernel_events = be.kernel_events, None
-        phases = {k: float(np.mean([a.elapsed_time(b) for (kk, a, b) in ev if kk == k]))
-                  for k in ("bmu", "accumulate", "smooth")}
-        return elapsed, phases
+        log, be.phase_log = np.array(be.phase_log), None
+        return elapsed, dict(zip(PHASES, log.mean(axis=0).tolist()))
 
 
-def frozen_map_regime(h, algorithm, X, W0, hop, sigma, gamma):
-    """every step = one full epoch from the SAME frozen prototypes."""
-    from dbgsom_amd import _native
-    from dbgsom_amd.backend import HipBackend
+def frozen_map_regime(h, algorithm, X, W0, hop, sigma, gamma, steps=None, warmup=None):
+    """every step = one full epoch from the SAME frozen prototypes (resident in HBM,
+    DBGSOM_EPOCH_FROZEN), new prototypes stay in HBM."""
+    from dbgsom_amd.backend import RESIDENT, HipBackend
 
     be = HipBackend(h.local, algorithm=algorithm)
+    be._set("timing", 1)
     be.load_device(X)
-    stage = None
-    if algorithm != "exact":
-        _native.call("dbgsom_filter_timing", 1)
-    last = {}
+    be.set_weights(W0)
+    M = W0.shape[0]
 
     def step():
-        last["res"] = be.epoch(W0, hop, sigma, gamma, "compact", False, keep_on_device=True)
+        be.epoch(RESIDENT, hop, sigma, gamma, "compact", False, keep_on_device=True, frozen=True)
 
-    elapsed, phases = h.timed_epochs(be, step, h.args.warmup, h.args.steps)
-    if algorithm != "exact":
-        ms = (ctypes.c_double * 5)()
-        _native.call("dbgsom_bmu_filtered_stage_ms", ms)
-        stage = dict(zip(("slice_w", "prepass", "bucket_sort", "sweep", "exact_on_candidates"),
-                         [float(v) for v in ms]))
-        _native.call("dbgsom_filter_timing", 0)
-        stage["sweep_planes"] = int(be._planes_used)   # what the adaptive policy settled on
+    elapsed, phases = h.timed_epochs(be, step, h.args.warmup if warmup is None else warmup,
+                                     h.args.steps if steps is None else steps)
+    info = {"filter_log": be.filter_log[-1] if be.filter_log else None}
+    counts = None
+    if be.filter_log and be.filter_log[-1][0] == "filtered":
         counts = be.filter_counts()
-        stage["candidates_per_workgroup"] = {"mean": float(counts.mean()),
-                                             "p90": float(np.percentile(counts, 90)),
-                                             "max": int(counts.max())}
-    wsum = float(last["res"].new_weights_dev.sum().item())
+        info["sweep_planes"] = int(be.filter_log[-1][2])
+        info["candidates_per_workgroup"] = count_stats(counts)
+    Wn = be.get_weights(1)   # the output of the last (frozen) epoch
     be.release()
-    return elapsed, phases, stage, wsum
+    del M
+    return elapsed, phases, info, counts, Wn
 
 
-def fine_phase_regime(h, X, W0, M, d, hop, gamma):
+def fine_phase_regime(h, X, W0, M, hop, gamma, n_total):
     """Secondary measurement: epochs of the FINE training phase (BaseSom.py:395-396, 899-900:
     constant sigma_end = max(0.7, 0.05 sqrt(M)), no growth) on a map that a decaying-sigma
-    warm-up has organised, prototypes evolving from step to step as in training.  Timed for the
-    exact search and for "auto" (previous winners as the filter's starting point).  Uses
-    centres_layout="aligned": with the reference's compacted centre rows (quirk Q1) a 32x32 map
-    with dead neurons scrambles itself into near-duplicate prototypes, which is not what a
+    warm-up has organised, prototypes evolving from step to step as in training and never leaving
+    HBM.  Timed for the exact search and for "auto" (previous winners as the filter's seeds).
+    Uses centres_layout="aligned": with the reference's compacted centre rows (quirk Q1) a 32x32
+    map with dead neurons scrambles itself into near-duplicate prototypes, which is not what a
     trained map looks like."""
-    from dbgsom_amd.backend import HipBackend
+    from dbgsom_amd.backend import RESIDENT, HipBackend
 
     sig0, sig1 = 0.2 * np.sqrt(M), max(0.7, 0.05 * np.sqrt(M))
     schedule = [sig1 + (sig0 - sig1) * np.exp(-0.35 * e) for e in range(14)]
     out = {"sigma": sig1, "warmup_epochs": len(schedule), "centres_layout": "aligned"}
-    wsum = {}
+    final = {}
     for algo in ("exact", "auto"):
         be = HipBackend(h.local, algorithm=algo)
+        be._set("timing", 1)
         be.load_device(X)
-        state = {"W": W0.clone()}
+        be.set_weights(W0)
         for s_ in schedule:  # untimed: organise the map
-            state["W"] = be.epoch(state["W"], hop, s_, gamma, "aligned", False,
-                                  keep_on_device=True).new_weights_dev
+            be.epoch(RESIDENT, hop, s_, gamma, "aligned", False, keep_on_device=True)
+        state = {}
 
         def step():
-            state["res"] = be.epoch(state["W"], hop, sig1, gamma, "aligned", False,
-                                    keep_on_device=True)
-            state["W"] = state["res"].new_weights_dev
+            state["res"] = be.epoch(RESIDENT, hop, sig1, gamma, "aligned", False, keep_on_device=True)
 
         elapsed, _ = h.timed_epochs(be, step, 0, h.args.steps)
         out[algo] = {"ms_per_step": elapsed / h.args.steps * 1e3,
-                     "value": X.shape[0] * h.world * h.args.steps / elapsed,
+                     "value": n_total * h.args.steps / elapsed,
                      "dead_neurons": int((state["res"].activations == 0).sum())}
-        if algo != "exact":
-            c = be.filter_counts()
-            out[algo]["candidates_per_workgroup"] = {"mean": float(c.mean()),
-                                                     "p90": float(np.percentile(c, 90)),
-                                                     "max": int(c.max())}
-        wsum[algo] = float(state["W"].sum().item())
+        if algo != "exact" and be.filter_log and be.filter_log[-1][0] == "filtered":
+            out[algo]["candidates_per_workgroup"] = count_stats(be.filter_counts())
+        final[algo] = be.get_weights(0)
         be.release()
-    out["prototypes_identical"] = wsum["exact"] == wsum["auto"]
+    out["prototypes_identical"] = bool(np.array_equal(final["exact"], final["auto"], equal_nan=True))
+    return out
+
+
+def other_data_regime(h, torch, device, name):
+    """The frozen-map step on a weakly clustered data set, `auto` (what a fit would run) beside
+    `exact`: which search `auto` settles on, how long the candidate lists are, and the rate."""
+    n, d, rows, cols, seed, kind, cfg_name = WORKLOADS[name]
+    M = rows * cols
+    X = make_shard(torch, n, d, seed, device, 0, kind)
+    g = torch.Generator(device=device).manual_seed(seed + 7)
+    W0 = X[torch.randperm(n, device=device, generator=g)[:M]].double().cpu().numpy()
+    gamma = float(1.0 / X.double().var(dim=0, unbiased=False).sum().item())
+    hop, sigma = lattice_hops(rows, cols), 0.2 * np.sqrt(M)
+    out = {"workload": cfg_name}
+    W = {}
+    for algo in ("auto", "filtered", "exact"):
+        steps = max(h.args.steps, 12) if algo == "auto" else h.args.steps   # auto: time to back off
+        el, ph, info, counts, W[algo] = frozen_map_regime(h, algo, X, W0, hop, sigma, gamma, steps=steps,
+                                                          warmup=10 if algo == "auto" else h.args.warmup)
+        out[algo] = {"value": n * steps / el, "ms_per_step": el / steps * 1e3, "bmu_ms": ph["bmu"],
+                     "last_epoch": info.get("filter_log")}
+        if counts is not None:
+            out[algo]["candidates_per_workgroup"] = count_stats(counts)
+            out[algo]["sweep_planes"] = info.get("sweep_planes")
+    out["prototypes_identical"] = bool(np.array_equal(W["exact"], W["auto"], equal_nan=True) and
+                                       np.array_equal(W["exact"], W["filtered"], equal_nan=True))
+    del X
+    torch.cuda.empty_cache()
     return out
 
 
@@ -239,16 +495,27 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the workload's N in total, N / G rows per rank (BASELINE's "
+                         "metric: N=1e6 sample-sharded 1/2/4/8); weak = the workload's N per rank")
+    ap.add_argument("--via", default="backend", choices=["backend", "ctx"],
+                    help="ctx: drive the context-level C ABI with NumPy + ctypes only (no torch)")
     ap.add_argument("--samples-per-gpu", type=int, default=None, help="override N per GPU")
     ap.add_argument("--algorithm", default="filtered", choices=["filtered", "exact"],
                     help="BMU search of the headline value (both give identical results)")
     ap.add_argument("--fine-phase", type=int, default=1,
                     help="also time a trained map in the fine phase (sigma_end, evolving W) with "
                          "the exact and the hinted filtered search (0 disables)")
+    ap.add_argument("--other-data", type=int, default=1,
+                    help="N = 1, workload c4: also run the weakly clustered data sets c4iso and c2nn")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="upper bound of rows timed by the CPU baseline (0 disables it); the "
                          "actual sample is sized for ~15 s of CPU work")
     args = ap.parse_args()
+    if args.via == "ctx":
+        if args.gpus != 1:
+            sys.exit("bench.py: --via ctx is the single-GPU NumPy caller")
+        return run_via_ctx(args)
 
     import torch
     import torch.distributed as td
@@ -285,96 +552,122 @@ def main():
             os.close(saved)
     h = Harness(torch, td, args, local, world, grouped)
 
-    n_gpu, d, rows, cols, seed, cfg_name = WORKLOADS[args.workload]
+    n_work, d, rows, cols, seed, kind, cfg_name = WORKLOADS[args.workload]
+    from dbgsom_amd.backend import shard_bounds
+
     if args.samples_per_gpu:
-        n_gpu = args.samples_per_gpu
+        n_gpu, n_total = args.samples_per_gpu, args.samples_per_gpu * world
+    elif args.scaling == "strong":
+        lo, hi = shard_bounds(n_work, rank, world)
+        n_gpu, n_total = hi - lo, n_work
+    else:
+        n_gpu, n_total = n_work, n_work * world
     M = rows * cols
-    X = make_shard(torch, n_gpu, d, seed, device, rank=rank)
+    X = make_shard(torch, n_gpu, d, seed, device, rank=rank, kind=kind)
+    xbytes = 4
     if args.workload in BF16_WORKLOADS:
-        X = X.to(torch.bfloat16)  # storage dtype of the workload; HipBackend.load_device keeps it
+        X = X.to(torch.bfloat16)  # storage dtype of the workload; the context keeps it
+        xbytes = 2
 
     # frozen map: M rows of rank 0's shard, Manhattan hop distances, epoch-0 sigma, gamma = 1/var
-    ctl = torch.zeros(M * d + 1, dtype=torch.float64, device=device)
+    # of the WHOLE data set (moments all-reduced)
+    mom = torch.zeros(2 * d + 1, dtype=torch.float64, device=device)
+    Xd = X.double() if n_gpu * d <= 4e8 else None
+    if Xd is not None:
+        mom[:d], mom[d:2 * d] = Xd.sum(dim=0), (Xd * Xd).sum(dim=0)
+    else:
+        for s in range(0, n_gpu, 100_000):
+            blk = X[s:s + 100_000].double()
+            mom[:d] += blk.sum(dim=0)
+            mom[d:2 * d] += (blk * blk).sum(dim=0)
+    del Xd
+    mom[2 * d] = n_gpu
+    if grouped:
+        td.all_reduce(mom)
+    nn = float(mom[2 * d].item())
+    var = mom[d:2 * d] / nn - (mom[:d] / nn) ** 2
+    gamma = float(1.0 / var.sum().item())
+    ctl = torch.zeros(M * d, dtype=torch.float64, device=device)
     if rank == 0:
         g = torch.Generator(device=device).manual_seed(seed + 7)
         sel = torch.randperm(n_gpu, device=device, generator=g)[:M]
-        ctl[:M * d] = X[sel].double().reshape(-1)
-        ctl[M * d] = 1.0 / X.double().var(dim=0, unbiased=False).sum()
+        ctl[:] = X[sel].double().reshape(-1)
     if grouped:
         td.broadcast(ctl, 0)
-    W0 = ctl[:M * d].reshape(M, d).contiguous()
-    gamma = float(ctl[M * d].item())
+    W0 = ctl.reshape(M, d).cpu().numpy()
     hop = lattice_hops(rows, cols)
     sigma = 0.2 * np.sqrt(M)  # BaseSom.py:876 at epoch 0
 
     results = {}
     for algo in dict.fromkeys([args.algorithm, "exact"]):  # headline first, exact always reported
         results[algo] = frozen_map_regime(h, algo, X, W0, hop, sigma, gamma)
-    fine = fine_phase_regime(h, X, W0, M, d, hop, gamma) if args.fine_phase else None
+    fine = fine_phase_regime(h, X, W0, M, hop, gamma, n_total) if args.fine_phase else None
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.samples_per_gpu:
+        # beside the metric's strong-scaling line: every rank with the workload's full N
+        Xw = make_shard(torch, n_work, d, seed, device, rank=rank, kind=kind)
+        if args.workload in BF16_WORKLOADS:
+            Xw = Xw.to(torch.bfloat16)
+        el, _, _, _, _ = frozen_map_regime(h, args.algorithm, Xw, W0, hop, sigma, gamma)
+        weak = {"samples_per_gpu": n_work, "value": n_work * world * args.steps / el,
+                "ms_per_step": el / args.steps * 1e3}
+        del Xw
 
+    out = None
     if rank == 0:
-        total = n_gpu * world
-        elapsed, phases, stage, wsum = results[args.algorithm]
-        e_elapsed, e_phases, _, e_wsum = results["exact"]
-        flops = 2.0 * n_gpu * M * d  # algorithmic flops of one BMU search
-        e_ach = flops / (e_phases["bmu"] * 1e-3) / 1e12
-        exact_roof = {"bound": "mfma", "kernel": "bmu_dma_kernel<float,1>", "dtype": "f64",
-                      "achieved": e_ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                      "frac": e_ach / F64_MFMA_PEAK_TFLOPS, "traffic": None,
-                      "kernel_ms": e_phases["bmu"]}
+        elapsed, phases, info, counts, Wn = results[args.algorithm]
+        e_elapsed, e_phases, _, _, e_Wn = results["exact"]
+        exact_roof = exact_roofline(n_gpu, d, M, e_phases["bmu"])
         if args.algorithm == "exact":
-            roof = exact_roof
+            roofs, roof = [exact_roof], exact_roof
         else:
-            dpad = (d + 63) // 64 * 64
-            planes = int(stage.get("sweep_planes", 2))
-            from dbgsom_amd import _native
-
-            small = planes == 1 and _native.load().dbgsom_sweep_shape(M, d) == 4
-            kernel = "sweep4_i8_kernel" if small else SWEEP_KERNEL[planes]
-            traffic = SWEEP4_TRAFFIC_C4_BYTES if small else SWEEP_TRAFFIC_C4_BYTES[planes]
-            ops = 2.0 * n_gpu * M * dpad * SWEEP_PRODUCTS[planes]  # int8 ops the sweep executes
-            ach = ops / (stage["sweep"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": kernel, "dtype": "i8",
-                    "achieved": ach, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
-                    "frac": ach / I8_MFMA_PEAK_TOPS,
-                    "traffic": traffic if args.workload == "c4" and
-                    n_gpu == WORKLOADS["c4"][0] else None,
-                    "kernel_ms": stage["sweep"], "digit_products": SWEEP_PRODUCTS[planes],
-                    "algorithmic_equiv_TFLOPs": flops / (stage["sweep"] * 1e-3) / 1e12}
+            roofs = rooflines(args.workload if n_gpu == n_work else None, n_gpu, d, M, xbytes, phases,
+                              int(info.get("sweep_planes", 1)), counts)
+            # the dominant kernel of the step = the longest stage that is one kernel family
+            roof = max(roofs[:2], key=lambda r: r["kernel_ms"]) if len(roofs) >= 2 else roofs[0]
         out = {
             "metric": "samples/sec/epoch (BMU+update)",
-            "value": total * args.steps / elapsed,
+            "value": n_total * args.steps / elapsed,
             "unit": "samples/s/epoch",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if (args.scaling == "weak" or args.samples_per_gpu) else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": cfg_name, "samples_per_gpu": n_gpu, "features": d,
-                       "prototypes": M, "x_storage": "bf16" if args.workload in BF16_WORKLOADS else "f32",
+            "config": {"workload": cfg_name, "samples_total": n_total, "samples_per_gpu": n_gpu,
+                       "features": d, "prototypes": M,
+                       "x_storage": "bf16" if args.workload in BF16_WORKLOADS else "f32",
                        "sharding": f"rows/{world}",
                        "map": "frozen (same prototypes every step)",
-                       "bmu_algorithm": args.algorithm},
+                       "bmu_algorithm": args.algorithm,
+                       "via": "HipBackend -> dbgsom_ctx_epoch (one C-ABI call per step)"},
             "roofline": roof,
-            "phases_ms": dict(phases, accumulate_GBps=n_gpu * d * 4 / (phases["accumulate"] * 1e-3) / 1e9),
+            "rooflines": roofs,
+            "build": source_hash(),
+            "phases_ms": phases,
         }
-        if stage:
-            out["filter_stages_ms"] = stage
-        out["exact"] = {"value": total * args.steps / e_elapsed,
+        if info.get("candidates_per_workgroup"):
+            out["filter"] = {"sweep_planes": info.get("sweep_planes"),
+                             "candidates_per_workgroup": info["candidates_per_workgroup"]}
+        out["exact"] = {"value": n_total * args.steps / e_elapsed,
                         "ms_per_step": e_elapsed / args.steps * 1e3, "phases_ms": e_phases,
                         "roofline": exact_roof,
-                        "prototypes_identical_to_headline": e_wsum == wsum}
+                        "prototypes_identical_to_headline": bool(np.array_equal(e_Wn, Wn, equal_nan=True))}
         if fine:
             out["fine_phase"] = fine
+        if weak:
+            out["weak_scaling_same_run"] = weak
+    if world == 1 and args.other_data and args.workload == "c4" and not args.samples_per_gpu:
+        out["other_data"] = {name: other_data_regime(h, torch, device, name) for name in ("c4iso", "c2nn")}
+    if rank == 0:
         if args.cpu_sample > 0 and world == 1:  # the CPU baseline is reported at N = 1 only
-            ns = min(args.cpu_sample, n_gpu)
-            out["cpu_baseline"] = cpu_baseline(args.workload, X[:ns].float().cpu().numpy(),
-                                               W0.cpu().numpy(), hop, sigma, gamma, n_gpu)
-            out["gpu_vs_cpu"] = (n_gpu * args.steps / elapsed) / out["cpu_baseline"]["value"]
+            ns = min(args.cpu_sample, X.shape[0])
+            out["cpu_baseline"] = cpu_baseline(X[:ns].float().cpu().numpy(), W0, hop, sigma, gamma, n_gpu)
+            out["gpu_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if grouped:
         td.barrier()

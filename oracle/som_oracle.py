@@ -258,6 +258,15 @@ def smooth_broadcast(h, a, C):
         return np.sum(C * inter, axis=1) / np.sum(inter, axis=1)
 
 
+def smooth_broadcast_rows(h, a, C, i0, i1):
+    """Output rows [i0, i1) of the literal form (BaseSom.py:509-515): the (rows, M, d) slice of
+    its (M, M, d) temporary -- lets a caller time / check the reference-faithful smoothing at
+    sizes where the whole temporary does not fit (bench.py's CPU leg)."""
+    inter = h[i0:i1, :, np.newaxis] * a[:, np.newaxis]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.sum(C * inter, axis=1) / np.sum(inter, axis=1)
+
+
 def change_total(W_old, W_new):
     """``sum_j |W_j - W'_j|_2`` (BaseSom.py:519-520)."""
     return float(np.sum(np.linalg.norm(W_old - W_new, axis=1)))

@@ -79,7 +79,7 @@ def test_full_size_c3_and_c2_properties():
     import bench
 
     for name in ("c3", "c2"):
-        n, d, rows, cols, seed, _ = bench.WORKLOADS[name]
+        n, d, rows, cols, seed, _, _ = bench.WORKLOADS[name]
         M = rows * cols
         dev = torch.device("cuda", 0)
         hip = HipBackend(0, algorithm="exact")
