@@ -45,14 +45,14 @@ class SomClassifier(BaseSom, TransformerMixin, ClassifierMixin):
 
     def predict(self, X) -> np.ndarray:
         check_is_fitted(self)
-        X = check_array(X)
+        X = check_array(X, dtype=[np.float64, np.float32])
         return self.classes_[np.argmax(self.predict_proba(X=X), axis=1)]
 
     def predict_proba(self, X) -> np.ndarray:
         """Class probabilities: sparse code over the prototypes times the prototypes' class
         frequencies, rows normalised (SomClassifier.py:178-220)."""
         check_is_fitted(self)
-        X = check_array(X)
+        X = check_array(X, dtype=[np.float64, np.float32])
         if self.vertical_growth:
             _, winners = self._get_winning_neurons(X, n_bmu=1)
             rows = []

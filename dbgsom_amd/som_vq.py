@@ -28,7 +28,9 @@ class SomVQ(BaseSom, ClusterMixin, TransformerMixin):
         """Index of the closest prototype for every sample (SomVQ.py:130-148)."""
         check_is_fitted(self)
         if not self._is_resident(X):
-            X = check_array(X)
+            # integer / half input is converted like the reference's engine does (sklearn's
+            # NearestNeighbors); float32 stays float32
+            X = check_array(X, dtype=[np.float64, np.float32])
         _, labels = self._get_winning_neurons(X, n_bmu=1)
         return labels
 

@@ -46,6 +46,10 @@ def case_X(name):
         Xt = np.random.default_rng(11).integers(0, 4, size=(600, 20)).astype(np.float64)
         Xt[300:] = Xt[:300]
         return Xt, None
+    if name == "vertical_blobs":
+        from sklearn.datasets import make_blobs
+
+        return make_blobs(n_samples=4000, n_features=10, centers=7, cluster_std=2.0, random_state=4)[0], None
     if name == "frozen_c2_f32":
         return blobs_f32(20000, 784, 1002)[0], None
     if name == "frozen_c3_f32":
@@ -72,7 +76,40 @@ EST_KWARGS = {
     "ties_int": dict(random_state=1, n_iter=12, max_neurons=30),
     "digits_entropy": dict(random_state=0, n_iter=30, growth_criterion="entropy",
                            spreading_factor=0.4, max_neurons=40),
+    "vertical_blobs": dict(random_state=2, vertical_growth=True, n_iter=24, max_neurons=9,
+                           min_samples_vertical_growth=150, spreading_factor=0.6),
 }
+
+
+def check_vertical_tree(est, g, rtol=1e-8):
+    """Compare a fitted estimator's tree of maps (vertical growth, BaseSom.py:157-179) with the
+    recorded one: same nodes carry children, every map has the recorded neurons / epochs /
+    prototypes / QE / TE / labels."""
+    import hashlib
+
+    paths = [list(g["paths_flat"][g["paths_off"][k]:g["paths_off"][k + 1]]) for k in range(int(g["n_maps"]))]
+    seen = []
+
+    def walk(e, path):
+        k = len(seen)
+        seen.append(path)
+        assert path == [int(v) for v in paths[k]], (path, paths[k])
+        assert [tuple(n) for n in g[f"map{k}_neurons"]] == e.neurons_, path
+        assert e.n_iter_ == int(g[f"map{k}_n_iter"]), path
+        np.testing.assert_allclose(e.weights_, g[f"map{k}_weights"], rtol=rtol, atol=1e-10)
+        np.testing.assert_allclose(e.quantization_error_, float(g[f"map{k}_qe"]), rtol=1e-9)
+        assert e.topographic_error_ == float(g[f"map{k}_te"]), path
+        assert len(e.labels_) == int(g[f"map{k}_n_samples"])
+        sha = hashlib.sha256(np.ascontiguousarray(e.labels_, dtype=np.int64).tobytes()).hexdigest()
+        assert sha == str(g[f"map{k}_labels_sha"]), path
+        np.testing.assert_allclose(e.growing_threshold_, float(g[f"map{k}_threshold"]), rtol=1e-12)
+        for i, node in enumerate(e.neurons_):
+            child = e.som_.nodes[node].get("som")
+            if child is not None:
+                walk(child, path + [i])
+
+    walk(est, [])
+    assert len(seen) == len(paths)
 
 
 def frozen_W(name, X):

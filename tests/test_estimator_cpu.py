@@ -205,3 +205,16 @@ def test_entropy_criterion_and_vertical_growth_run():
                spreading_factor=0.9, min_samples_vertical_growth=50,
                backend=OracleBackend()).fit(X)
     assert len(vq.neurons_) >= 4
+
+
+def test_vertical_growth_builds_the_tree_the_reference_means_to():
+    """vertical_growth=True.  The reference as it stands raises (recorded in the fixture: its
+    comprehension compares a (node, error) tuple with a float); the fixture's tree of maps is what
+    its _grow_vertical evidently means, made with those slips corrected (tools/make_golden.py).
+    Host path (X[winners == j]) through the oracle's CPU backend."""
+    g = gi.load("vertical_blobs")
+    assert "TypeError" in str(g["reference_raises"])
+    X, _ = gi.case_X("vertical_blobs")
+    est = SomVQ(backend=OracleBackend("sklearn"), **gi.EST_KWARGS["vertical_blobs"]).fit(X)
+    assert int(g["n_maps"]) > 1
+    gi.check_vertical_tree(est, g)

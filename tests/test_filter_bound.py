@@ -28,7 +28,8 @@ def r_tilde(X, W, levels=3):
     P0 = x0 @ w0.T
     P1 = x0 @ w1.T + x1 @ w0.T
     P2 = x0 @ w2.T + x1 @ w1.T + x2 @ w0.T
-    T = (P0 * 256 + P1) * 256 + (P2 if levels == 3 else 0)
+    # kept digit products: levels == 3 all with a + b <= 2 (six), 2: a + b <= 1 (three), 1: (0, 0) only
+    T = (P0 * 256 + (P1 if levels >= 2 else 0)) * 256 + (P2 if levels == 3 else 0)
     xx = (X.astype(np.float64) ** 2).sum(axis=1)
     yy = (W.astype(np.float64) ** 2).sum(axis=1)
     ctab = 2.0 * tw * 65536.0 / (F * F)
@@ -38,7 +39,10 @@ def r_tilde(X, W, levels=3):
 
 def filter_eps(s, l1x, xx, l1w_max, t_max, yy_max, d, planes=3):
     quant = (s * l1w_max + t_max * l1x) / (2.0 * F) + d * s * t_max / (4.0 * F * F)
-    per_k = 16384.0 * (513.0 if planes >= 3 else 3.0 * 65536.0 + 513.0)
+    # dropped digit products per feature in units of 128 * 128 (filter.hip `filter_eps`): levels
+    # 3 and 4 always; level 2 (three products) below three planes; level 1 (two) with one plane
+    per_k = 16384.0 * (513.0 if planes >= 3 else 3.0 * 65536.0 + 513.0 if planes == 2
+                       else 2.0 * 16777216.0 + 3.0 * 65536.0 + 513.0)
     dropped = d * per_k * s * t_max / (F * F)
     rounding = 4.0 * (d + 16) * 1.1102230246251565e-16 * (xx + yy_max)
     return 2.0 * (quant + dropped) * (1.0 + 1e-7) + rounding
@@ -60,23 +64,35 @@ CASES = [
                                                          rng.normal(size=(50, 32)) * 1e6]).astype(np.float32),
                                         np.concatenate([rng.normal(size=(20, 32)) * 1e-6,
                                                         rng.normal(size=(20, 32)) * 1e6]))),
+    # adversarial for the coarse sweeps: a tiny spread around a large mean (every top digit equal)
+    ("tiny_spread_large_mean", lambda rng: (rng.uniform(0.45, 0.55, size=(300, 128)).astype(np.float32),
+                                            rng.uniform(0.45, 0.55, size=(90, 128)))),
+    ("offset_blobs", lambda rng: ((100.0 + (rng.normal(size=(5, 80)))[rng.integers(0, 5, 250)]
+                                   + 0.01 * rng.normal(size=(250, 80))).astype(np.float32),
+                                  100.0 + rng.normal(size=(70, 80)))),
 ]
 
 
-@pytest.mark.parametrize("name", ["gauss", "blobs", "heavy_tail", "tiny_and_huge_rows"])
+@pytest.mark.parametrize("name", [c[0] for c in CASES])
 def test_r_tilde_stays_inside_the_bound(name):
     rng = np.random.default_rng(abs(hash(name)) % 2 ** 32)
     X, W = dict((c[0], c[1]) for c in CASES)[name](rng)
     X = np.asarray(X, dtype=np.float32).astype(np.float64)
     W = np.asarray(W, dtype=np.float64)
     r = exact_r(X, W)
-    for planes in (3, 2):
+    for planes in (3, 2, 1):     # 1 = the one-product sweep the shipped default starts with
         rt, (sx, l1x, xx, tw, l1w, yy) = r_tilde(X, W, levels=planes)
         eps = filter_eps(sx, l1x, xx, l1w.max(), tw.max(), yy.max(), X.shape[1], planes)
         err = np.abs(rt - r)
         assert (err <= eps[:, None]).all(), (planes, float((err / eps[:, None]).max()))
         # the bound is not absurdly loose either (within ~3-4 orders of magnitude of the worst error)
         assert (err / eps[:, None]).max() > 1e-5
+        # and the candidate rule built on it keeps every prototype that can win or tie, any seed
+        n = X.shape[0]
+        for seeds in (r.argmin(1), rng.integers(0, W.shape[0], n)):
+            thr = rt[np.arange(n), seeds] + 2 * eps
+            must = r <= r[np.arange(n), seeds][:, None]
+            assert ((rt <= thr[:, None]) | ~must).all(), planes
 
 
 def test_spiky_rows_and_zero_rows():

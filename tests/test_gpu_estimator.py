@@ -46,6 +46,106 @@ def test_known_answers_digits_gpu():
     assert est.labels_[:10].tolist() == [23, 16, 6, 18, 19, 14, 17, 2, 21, 5]
 
 
+def test_predict_accepts_integer_and_half_input_like_the_reference():
+    """fit(X_int) converts to float64; predict / calculate_quantization_error on the same integer
+    (or float16) array must too -- the reference's engine (sklearn NearestNeighbors) does."""
+    from dbgsom_amd import SomClassifier, SomVQ
+    from dbgsom_amd.backend import HipBackend
+
+    Xi, y = gi.case_X("ties_int")
+    Xi = np.rint(Xi).astype(np.int64)
+    est = SomVQ(random_state=1, n_iter=12).fit(Xi)
+    lab = est.predict(Xi)
+    assert np.array_equal(lab, est.labels_) and np.array_equal(lab, est.predict(Xi.astype(np.float64)))
+    assert np.array_equal(est.predict(Xi.astype(np.uint8)), lab)
+    assert np.array_equal(est.predict(Xi.astype(np.float16)), lab)
+    qe = est.calculate_quantization_error(Xi)
+    assert qe == est.calculate_quantization_error(Xi.astype(np.float64))
+    d, i = HipBackend().bmu(est.weights_, 1, X=Xi)       # the backend converts too
+    assert np.array_equal(i, lab)
+    Xd, yd = gi.case_X("digits_clf")
+    clf = SomClassifier(random_state=0, n_iter=10).fit(Xd, yd)
+    assert np.array_equal(clf.predict(Xd.astype(np.int32)), clf.predict(Xd))
+
+
+def test_full_size_c5_shard_properties():
+    """One GPU's shard of BASELINE config C5 at its real shape (N = 5e5, d = 2048, M = 4096,
+    bfloat16-resident samples): the filtered search equals the all-pairs search on the full
+    arrays, an oracle spot check on 1000 rows of the rounded samples, conservation sums."""
+    import torch
+
+    import bench
+    from dbgsom_amd.backend import HipBackend
+    from oracle import som_oracle as o
+
+    n, d, rows, cols, seed, kind, _ = bench.WORKLOADS["c5"]
+    M = rows * cols
+    dev = torch.device("cuda", 0)
+    X = bench.make_shard(torch, n, d, seed, dev, 0, kind).to(torch.bfloat16)
+    g = torch.Generator(device=dev).manual_seed(seed + 7)
+    W = X[torch.randperm(n, device=dev, generator=g)[:M]].double().cpu().numpy()
+    gamma = float(1.0 / X.float().var(dim=0, unbiased=False).double().sum().item())
+    hop, sigma = bench.lattice_hops(rows, cols), 0.2 * np.sqrt(M)
+    out = {}
+    for algo in ("filtered", "exact"):
+        be = HipBackend(0, algorithm=algo).load_device(X)
+        assert be._x_np_dtype == "bf16"
+        out[algo] = be.epoch(W, hop, sigma, gamma, "compact", True)
+        if algo == "filtered":
+            assert be.filter_log[-1][0] == "filtered" and be.planes_cached
+            sums = be.read_sums(M)
+        be.release()
+    rf, re_ = out["filtered"], out["exact"]
+    assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances)
+    assert np.array_equal(rf.new_weights, re_.new_weights, equal_nan=True)
+    assert np.array_equal(rf.errors, re_.errors) and rf.change_total == re_.change_total
+    pick = np.random.default_rng(1).choice(n, 1000, replace=False)
+    Xs = X[torch.from_numpy(pick).to(dev)].float().cpu().numpy()     # the exactly widened rows
+    rd, ri = o.bmu_chain(Xs, W, 1)
+    assert np.array_equal(rf.winners[pick], ri) and np.array_equal(rf.distances[pick], rd)
+    # conservation: hits sum to N, E to sum(dist), K to sum(kw), S to kw^T X
+    assert rf.activations.sum() == n
+    np.testing.assert_allclose(rf.errors.sum(), rf.distances.sum(), rtol=1e-10)
+    kw = 1 - np.sqrt(1 - np.exp(-gamma * rf.distances ** 2))
+    S = sums[: M * d].reshape(M, d)
+    np.testing.assert_allclose(sums[M * d: M * d + M].sum(), kw.sum(), rtol=1e-10)
+    col = torch.zeros(d, dtype=torch.float64, device=dev)
+    kwd = torch.from_numpy(kw).to(dev)
+    for s in range(0, n, 50_000):
+        col += kwd[s:s + 50_000] @ X[s:s + 50_000].double()
+    np.testing.assert_allclose(S.sum(axis=0), col.cpu().numpy(), rtol=1e-9, atol=1e-9)
+
+
+def test_vertical_growth_on_device_subsets_matches_the_recorded_tree():
+    """vertical_growth=True on the MI355X: the Voronoi sets are gathered in HBM
+    (dbgsom_ctx_partition / dbgsom_ctx_subset_create), the children are fitted on them without a
+    host copy or a second upload; the tree equals the one recorded from the reference (its two
+    slips in _grow_vertical corrected; as it stands it raises -- also recorded)."""
+    from dbgsom_amd import SomVQ
+    from dbgsom_amd import base as base_mod
+
+    g = gi.load("vertical_blobs")
+    assert "TypeError" in str(g["reference_raises"])
+    X, _ = gi.case_X("vertical_blobs")
+    seen = []
+    orig = base_mod.BaseSom._load_resident
+
+    def spy(self, data):
+        seen.append(type(data).__name__)
+        return orig(self, data)
+
+    base_mod.BaseSom._load_resident = spy
+    try:
+        est = SomVQ(**gi.EST_KWARGS["vertical_blobs"]).fit(X)
+    finally:
+        base_mod.BaseSom._load_resident = orig
+    gi.check_vertical_tree(est, g)
+    assert seen[0] == "ndarray" and set(seen[1:]) == {"DeviceSamples"} and len(seen) == int(g["n_maps"])
+    # float32 samples take the same route
+    est32 = SomVQ(**gi.EST_KWARGS["vertical_blobs"]).fit(X.astype(np.float32))
+    assert any("som" in est32.som_.nodes[n] for n in est32.neurons_)
+
+
 def test_bench_under_torchrun_single_rank_rccl():
     """Rehearsal of the multi-GPU launch on a one-GPU box: torch.distributed.run with one rank,
     the RCCL group is created and the per-epoch all-reduce is actually issued

@@ -226,6 +226,73 @@ def run_fit_case(name, make_est, X, y, epochs_full, extra_meta):
     return meta
 
 
+def _intended_grow_vertical(self, X, y=None):
+    """BaseSom._grow_vertical (BaseSom.py:157-179) with its two slips corrected -- OUR restatement
+    of the evident intent, not reference text: the comprehension unpacks (node, error) instead of
+    comparing the tuple with a float, and the child is stored under the node's key instead of its
+    position.  Everything a child does (clone, fit on X[winners == i]) is the reference's own."""
+    from sklearn.base import clone
+
+    self.vertical_growing_threshold_ = 1.5 * self.growing_threshold_
+    _, winners = self._get_winning_neurons(X, n_bmu=1)
+    relevant = [i for i, (_node, error) in enumerate(self.som_.nodes(data="error"))
+                if error > self.vertical_growing_threshold_]
+    for i in relevant:
+        new_som = clone(self)
+        X_f = X[winners == i]
+        y_f = None if y is None else y[winners == i]
+        if X_f.shape[0] > self.min_samples_vertical_growth:
+            new_som.fit(X_f, y_f)
+            self.som_.nodes[self.neurons_[i]]["som"] = new_som
+
+
+def _walk_maps(est, path, out):
+    k = len(out["paths"])
+    out["paths"].append(list(path))
+    out[f"map{k}_weights"] = est.weights_
+    out[f"map{k}_neurons"] = np.array(est.neurons_, dtype=np.int64)
+    out[f"map{k}_n_iter"] = np.int64(est.n_iter_)
+    out[f"map{k}_qe"] = np.float64(est.quantization_error_)
+    out[f"map{k}_te"] = np.float64(est.topographic_error_)
+    out[f"map{k}_labels_sha"] = np.array(sha(np.asarray(est.labels_, dtype=np.int64)))
+    out[f"map{k}_n_samples"] = np.int64(len(est.labels_))
+    out[f"map{k}_threshold"] = np.float64(est.growing_threshold_)
+    for i, node in enumerate(est.neurons_):
+        child = est.som_.nodes[node].get("som")
+        if child is not None:
+            _walk_maps(child, path + [i], out)
+
+
+def run_vertical_case(name, make_est, X, extra_meta):
+    """vertical_growth=True: (1) what the reference does as it stands, (2) the tree of maps it
+    evidently means to build (the two slips of _grow_vertical corrected, see above)."""
+    t0 = time.time()
+    raised = ""
+    try:
+        make_est().fit(X)
+    except Exception as e:  # noqa: BLE001 -- recorded, that IS the reference's behaviour
+        raised = f"{type(e).__name__}: {e}"
+    orig = ref_base.BaseSom._grow_vertical
+    ref_base.BaseSom._grow_vertical = _intended_grow_vertical
+    try:
+        est = make_est().fit(X)
+    finally:
+        ref_base.BaseSom._grow_vertical = orig
+    out = {"paths": []}
+    _walk_maps(est, [], out)
+    paths = out.pop("paths")
+    out["n_maps"] = np.int64(len(paths))
+    out["paths_flat"] = np.array([p for path in paths for p in path], dtype=np.int64)
+    out["paths_off"] = np.cumsum([0] + [len(p) for p in paths])
+    out["reference_raises"] = np.array(raised)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    meta = {"wall_s": round(time.time() - t0, 2), "n_maps": len(paths), "paths": paths,
+            "reference_as_is": raised or "no exception"}
+    meta.update(extra_meta)
+    print(name, meta, flush=True)
+    return meta
+
+
 def blobs_f32(n, d, seed, n_centers=32, scale=4.0):
     """Synthetic generator shared with bench.py / tests."""
     rng = np.random.default_rng(seed)
@@ -340,6 +407,17 @@ def main():
             {"X": "load_digits() data/target [:900]",
              "est": "SomClassifier(random_state=0, n_iter=30, growth_criterion='entropy', "
                     "spreading_factor=0.4, max_neurons=40)"},
+        )
+    if not only or "vertical_blobs" in only:
+        Xv = make_blobs(n_samples=4000, n_features=10, centers=7, cluster_std=2.0, random_state=4)[0]
+        manifest["cases"]["vertical_blobs"] = run_vertical_case(
+            "vertical_blobs",
+            lambda: SomVQ(random_state=2, vertical_growth=True, n_iter=24, max_neurons=9,
+                          min_samples_vertical_growth=150, spreading_factor=0.6),
+            Xv,
+            {"X": "make_blobs(n_samples=4000, n_features=10, centers=7, cluster_std=2.0, random_state=4)[0]",
+             "est": "SomVQ(random_state=2, vertical_growth=True, n_iter=24, max_neurons=9, "
+                    "min_samples_vertical_growth=150, spreading_factor=0.6)"},
         )
     if only:
         with open(mpath, "w") as f:
