@@ -28,6 +28,7 @@ struct AccWs {
     uint32_t *chunk_pre;  // M + 1      exclusive scan of ceil(count / CH)
     double *slab;         // maxchunks * (d + 2)   [partial S | partial K | partial E]
     double *gslab;        // M * finalize_groups(M) * (d + 2): second level of the ordered sum
+    uint32_t *ticket;     // "last workgroup" ticket of the fused column / segment scan
     int64_t nb, maxchunks;
 };
 
@@ -51,7 +52,9 @@ static size_t carve(AccWs *w, char *base, int64_t N, int64_t d, int64_t M) {
     const size_t o_chunk = take((size_t)(M + 1) * 4);
     const size_t o_slab = take((size_t)maxchunks * (d + 2) * 8);
     const size_t o_gslab = take((size_t)M * finalize_groups(M) * (d + 2) * 8);
+    const size_t o_ticket = take(256);
     if (w) {
+        w->ticket = (uint32_t *)(base + o_ticket);
         w->order = (int32_t *)(base + o_order);
         w->blk = (uint32_t *)(base + o_blk);
         w->count = (uint32_t *)(base + o_count);
@@ -73,8 +76,10 @@ size_t accumulate_workspace_bytes(int64_t N, int64_t d, int64_t M) {
 // ---- 1. per-workgroup histogram of winners ---------------------------------------------------
 __global__ __launch_bounds__(AT) void hist_kernel(const int64_t *__restrict__ win, int64_t N,
                                                   int M, uint32_t *__restrict__ blk,
-                                                  int32_t *__restrict__ status) {
+                                                  int32_t *__restrict__ status,
+                                                  uint32_t *__restrict__ ticket) {
     extern __shared__ uint32_t h[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;  // of the scan kernel that follows
     for (int j = threadIdx.x; j < M; j += AT) h[j] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * HS;
@@ -96,9 +101,8 @@ __global__ __launch_bounds__(AT) void hist_kernel(const int64_t *__restrict__ wi
 // a group of consecutive workgroups each, prefix over the groups in LDS, then every thread rewrites
 // its group) -- 8 x fewer dependent load rounds than one thread per column.
 constexpr int CS_COLS = 32, CS_GROUPS = 8;
-__global__ __launch_bounds__(CS_COLS * CS_GROUPS) void colscan_kernel(uint32_t *__restrict__ blk,
-                                                                      int64_t nb, int M,
-                                                                      uint32_t *__restrict__ count) {
+__device__ __forceinline__ void colscan_body(uint32_t *__restrict__ blk, int64_t nb, int M,
+                                             uint32_t *__restrict__ count) {
     __shared__ uint32_t part[CS_GROUPS][CS_COLS];
     const int c = threadIdx.x % CS_COLS, g = threadIdx.x / CS_COLS;
     const int j = blockIdx.x * CS_COLS + c;
@@ -137,17 +141,19 @@ __global__ __launch_bounds__(CS_COLS * CS_GROUPS) void colscan_kernel(uint32_t *
     }
 }
 
-// ---- 3. exclusive scans over the M neurons (one workgroup) -----------------------------------
-__global__ __launch_bounds__(1024) void segscan_kernel(const uint32_t *__restrict__ count, int M,
-                                                       uint32_t *__restrict__ seg_start,
-                                                       uint32_t *__restrict__ chunk_pre) {
-    __shared__ uint32_t wa[16], wb[16];
+// ---- 3. exclusive scans over the M neurons (one workgroup of NTHR threads) ----------------------
+template <int NTHR>
+__device__ __forceinline__ void segscan_body(const uint32_t *__restrict__ count, int M,
+                                             uint32_t *__restrict__ seg_start,
+                                             uint32_t *__restrict__ chunk_pre) {
+    constexpr int NWAVE = NTHR / 64;
+    __shared__ uint32_t wa[NWAVE], wb[NWAVE];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int per = (M + 1023) / 1024;
+    const int per = (M + NTHR - 1) / NTHR;
     const int lo = min(M, t * per), hi = min(M, lo + per);
     uint32_t a = 0, b = 0;
     for (int j = lo; j < hi; ++j) { a += count[j]; b += (count[j] + CH - 1) / CH; }
-    uint32_t ia = a, ib = b;  // inclusive scan over the wavefront, then over the 16 wavefronts
+    uint32_t ia = a, ib = b;  // inclusive scan over the wavefront, then over the wavefronts
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t va = __shfl_up(ia, off, 64), vb = __shfl_up(ib, off, 64);
@@ -157,12 +163,23 @@ __global__ __launch_bounds__(1024) void segscan_kernel(const uint32_t *__restric
     __syncthreads();
     uint32_t pa = 0, pb = 0;
     for (int u = 0; u < wv; ++u) { pa += wa[u]; pb += wb[u]; }
-    if (t == 1023) { seg_start[M] = pa + ia; chunk_pre[M] = pb + ib; }
+    if (t == NTHR - 1) { seg_start[M] = pa + ia; chunk_pre[M] = pb + ib; }
     a = pa + ia - a; b = pb + ib - b;  // exclusive prefix of this thread's range
     for (int j = lo; j < hi; ++j) {
         seg_start[j] = a; chunk_pre[j] = b;
         a += count[j]; b += (count[j] + CH - 1) / CH;
     }
+}
+
+// column scan (2.) and, in the workgroup that finishes last, the scans over the neurons (3.): they
+// need every column's count, and a kernel of their own is one 5 us launch more per sort
+__global__ __launch_bounds__(CS_COLS * CS_GROUPS) void scan_kernel(uint32_t *__restrict__ blk, int64_t nb, int M,
+                                                                   uint32_t *__restrict__ count,
+                                                                   uint32_t *__restrict__ seg_start,
+                                                                   uint32_t *__restrict__ chunk_pre,
+                                                                   uint32_t *__restrict__ ticket) {
+    colscan_body(blk, nb, M, count);
+    if (last_workgroup_done(ticket, gridDim.x)) segscan_body<CS_COLS * CS_GROUPS>(count, M, seg_start, chunk_pre);
 }
 
 // ---- 4. stable scatter of sample ids into their neuron's segment -----------------------------
@@ -236,7 +253,7 @@ __device__ __forceinline__ void load_vec(const XT *__restrict__ src, double (&v)
 template <typename XT, int VEC>
 __global__ __launch_bounds__(AT) void segsum_kernel(
     const XT *__restrict__ X, int d, int64_t ldx, const int32_t *__restrict__ order,
-    const double *__restrict__ kw, const double *__restrict__ dist,
+    const double *__restrict__ kw, double gamma, const double *__restrict__ dist,
     const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ count,
     const uint32_t *__restrict__ chunk_pre, int M, double *__restrict__ slab) {
     __shared__ int32_t rows_s[CH];
@@ -263,8 +280,11 @@ __global__ __launch_bounds__(AT) void segsum_kernel(
     if (tid < n) {
         const int32_t r = order[begin + tid];
         rows_s[tid] = r;
-        kw_s[tid] = kw[r];
-        dist_s[tid] = dist[r];
+        const double dd = dist[r];
+        // kw == nullptr: the sample kernel of BaseSom._calculate_exp_similarity (BaseSom.py:533-538)
+        // on the fly, the arithmetic of exp_similarity_kernel (bmu.hip)
+        kw_s[tid] = kw ? kw[r] : 1.0 - sqrt(1.0 - exp(-gamma * (dd * dd)));
+        dist_s[tid] = dd;
     }
     __syncthreads();
     double *out = slab + (size_t)c * (d + 2);
@@ -328,8 +348,12 @@ __global__ __launch_bounds__(AT) void finalize_kernel(const double *__restrict__
                                                       int M, const uint32_t *__restrict__ count,
                                                       const uint32_t *__restrict__ chunk_pre,
                                                       int NG, double *__restrict__ gslab,
-                                                      double *__restrict__ sums) {
+                                                      double *__restrict__ sums,
+                                                      const int32_t *__restrict__ status,
+                                                      double *__restrict__ status_f64) {
     const int j = blockIdx.x, g = blockIdx.y;
+    if (status_f64 && j == 0 && g == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        status_f64[0] = status[0] ? 1.0 : 0.0;   // the flag rides behind the sums in the all-reduce buffer
     const uint32_t b0 = chunk_pre[j], b1 = chunk_pre[j + 1];
     const uint32_t per = (b1 - b0 + NG - 1) / NG;  // chunks per group
     const uint32_t c0 = min(b1, b0 + g * per), c1 = min(b1, c0 + per);
@@ -382,7 +406,7 @@ static int key_bits(int64_t M) {  // bits that tell the keys 0 .. M - 1 apart
 // samples in this order).  `ws` needs bucket_sort_workspace_bytes(N, M); `order` gets N int32.
 size_t bucket_sort_workspace_bytes(int64_t N, int64_t M) {
     const int64_t nb = (N + HS - 1) / HS;
-    return align_up((size_t)nb * M * 4) + align_up((size_t)M * 4) + 2 * align_up((size_t)(M + 1) * 4);
+    return align_up((size_t)nb * M * 4) + align_up((size_t)M * 4) + 2 * align_up((size_t)(M + 1) * 4) + 256;
 }
 
 int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order, void *ws,
@@ -396,31 +420,34 @@ int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order,
     uint32_t *seg_start = (uint32_t *)base;
     base += align_up((size_t)(M + 1) * 4);
     uint32_t *chunk_pre = (uint32_t *)base;
+    base += align_up((size_t)(M + 1) * 4);
+    uint32_t *ticket = (uint32_t *)base;
     const int Mi = (int)M;
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)nb), dim3(AT), (size_t)M * 4, s, idx, N, Mi, blk,
-                       (int32_t *)nullptr);
-    hipLaunchKernelGGL(colscan_kernel, dim3((unsigned)((M + CS_COLS - 1) / CS_COLS)),
-                       dim3(CS_COLS * CS_GROUPS), 0, s, blk, nb, Mi, count);
-    hipLaunchKernelGGL(segscan_kernel, dim3(1), dim3(1024), 0, s, count, Mi, seg_start, chunk_pre);
+                       (int32_t *)nullptr, ticket);
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)((M + CS_COLS - 1) / CS_COLS)),
+                       dim3(CS_COLS * CS_GROUPS), 0, s, blk, nb, Mi, count, seg_start, chunk_pre, ticket);
     hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nb), dim3(SCW), (size_t)M * 4, s, idx, N, Mi,
                        key_bits(M), blk, seg_start, order);
     return launch_status("bucket sort kernels");
 }
 
 // ---------------------------------------------------------------------------------------------
-int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
-                      const int64_t *idx, const double *kw, const double *dist, int64_t M,
-                      double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s) {
+static int accumulate_impl(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                           const int64_t *idx, const double *kw, double gamma, const double *dist, int64_t M,
+                           double *sums, int32_t *status, bool status_behind_sums, void *ws,
+                           size_t ws_bytes, hipStream_t s) {
     DBGSOM_REQUIRE(valid_dtype(x_dtype), "x_dtype must be DBGSOM_F32/F64/BF16");
     DBGSOM_REQUIRE(N >= 0 && N < 0x7fffffff && d >= 1 && d <= 0x7ffffff0 && ldx >= d, "bad sample shape");
     DBGSOM_REQUIRE(M >= 1 && M <= DBGSOM_MAX_PROTOTYPES, "M outside [1, DBGSOM_MAX_PROTOTYPES]");
     DBGSOM_REQUIRE(sums, "null sums");
+    DBGSOM_REQUIRE(!status_behind_sums || status, "the status flag is needed behind the sums");
     if (status) DBGSOM_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), s));
     if (N == 0) {
-        DBGSOM_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)M * (d + 3) * sizeof(double), s));
+        DBGSOM_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)(M * (d + 3) + (status_behind_sums ? 1 : 0)) * sizeof(double), s));
         return DBGSOM_OK;
     }
-    DBGSOM_REQUIRE(X && idx && kw && dist && ws, "null pointer");
+    DBGSOM_REQUIRE(X && idx && dist && ws, "null pointer");
     DBGSOM_REQUIRE(is_aligned(ws, 256), "workspace must be 256-byte aligned");
     if (ws_bytes < accumulate_workspace_bytes(N, d, M)) {
         set_error("dbgsom_accumulate: workspace too small (%zu < %zu)", ws_bytes,
@@ -432,11 +459,10 @@ int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t 
     const int Mi = (int)M, di = (int)d;
 
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)w.nb), dim3(AT), (size_t)M * 4, s, idx, N, Mi,
-                       w.blk, status);
-    hipLaunchKernelGGL(colscan_kernel, dim3((unsigned)((M + CS_COLS - 1) / CS_COLS)),
-                       dim3(CS_COLS * CS_GROUPS), 0, s, w.blk, w.nb, Mi, w.count);
-    hipLaunchKernelGGL(segscan_kernel, dim3(1), dim3(1024), 0, s, w.count, Mi, w.seg_start,
-                       w.chunk_pre);
+                       w.blk, status, w.ticket);
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)((M + CS_COLS - 1) / CS_COLS)),
+                       dim3(CS_COLS * CS_GROUPS), 0, s, w.blk, w.nb, Mi, w.count, w.seg_start, w.chunk_pre,
+                       w.ticket);
     hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)w.nb), dim3(SCW), (size_t)M * 4, s,
                        idx, N, Mi, key_bits(M), w.blk, w.seg_start, w.order);
 
@@ -445,7 +471,7 @@ int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t 
     dim3 grid((unsigned)w.maxchunks), block(AT);
 #define DBGSOM_SEGSUM(XT, V)                                                                    \
     hipLaunchKernelGGL((segsum_kernel<XT, V>), grid, block, 0, s, (const XT *)X, di, ldx, w.order, \
-                       kw, dist, w.seg_start, w.count, w.chunk_pre, Mi, w.slab)
+                       kw, gamma, dist, w.seg_start, w.count, w.chunk_pre, Mi, w.slab)
     if (x_dtype == DBGSOM_F32) {
         if (al16 && d % 4 == 0) DBGSOM_SEGSUM(float, 4); else DBGSOM_SEGSUM(float, 1);
     } else if (x_dtype == DBGSOM_F64) {
@@ -457,11 +483,25 @@ int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t 
     const int NG = finalize_groups(M);
     const unsigned col_blocks = (unsigned)((d + 2 + AT - 1) / AT < 8 ? (d + 2 + AT - 1) / AT : 8);
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)M, (unsigned)NG, col_blocks), dim3(AT), 0, s, w.slab, di, Mi,
-                       w.count, w.chunk_pre, NG, w.gslab, sums);
+                       w.count, w.chunk_pre, NG, w.gslab, sums, (const int32_t *)status,
+                       status_behind_sums ? sums + (size_t)M * (d + 3) : (double *)nullptr);
     if (NG > 1)
         hipLaunchKernelGGL(finalize_groups_kernel, dim3((unsigned)M), dim3(AT), 0, s, w.gslab, di, Mi, NG,
                            sums);
     return launch_status("accumulate kernels");
+}
+
+int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                      const int64_t *idx, const double *kw, const double *dist, int64_t M,
+                      double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s) {
+    DBGSOM_REQUIRE(N == 0 || kw, "null sample weights");
+    return accumulate_impl(X, x_dtype, N, d, ldx, idx, kw, 0.0, dist, M, sums, status, false, ws, ws_bytes, s);
+}
+
+int launch_accumulate_epoch(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                            const int64_t *idx, double gamma, const double *dist, int64_t M,
+                            double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s) {
+    return accumulate_impl(X, x_dtype, N, d, ldx, idx, nullptr, gamma, dist, M, sums, status, true, ws, ws_bytes, s);
 }
 
 }  // namespace dbgsom

@@ -50,6 +50,35 @@ __device__ __forceinline__ double widen(double v) { return v; }
 __device__ __forceinline__ double widen(float v) { return (double)v; }
 __device__ __forceinline__ double widen(bf16_t v) { return (double)(float)v; }
 
+// "The last workgroup to finish does the follow-up step": folds a tiny dependent kernel (a scan
+// over M entries, a final reduction) into the launch that produces its input -- a 4-5 us launch
+// less per use.  Every workgroup calls this after its last global store; it returns true (in all
+// threads) in exactly one workgroup, the one whose ticket is the last, and by then every other
+// workgroup's stores are visible to it: plain stores -> every wave's vmcnt(0) -> barrier ->
+// agent-scope release -> ticket (relaxed agent atomic); the last arriver: agent-scope acquire
+// (invalidates this CU's L1) -> vmcnt(0) -> barrier -> plain loads (MI355X_MICROARCH.md,
+// "Workgroup dispatch, XCD placement & inter-workgroup visibility").  The ticket counter must be 0
+// before the launch; the last workgroup leaves it at 0 again.
+__device__ __forceinline__ bool last_workgroup_done(uint32_t *ticket, uint32_t n_workgroups) {
+    __shared__ int is_last_;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == n_workgroups - 1u);
+        if (last) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        is_last_ = last;
+    }
+    __syncthreads();
+    return is_last_ != 0;
+}
+
 inline bool valid_dtype(int dt) { return dt == DBGSOM_F32 || dt == DBGSOM_F64 || dt == DBGSOM_BF16; }
 inline size_t dtype_size(int dt) { return dt == DBGSOM_F64 ? 8 : (dt == DBGSOM_F32 ? 4 : 2); }
 
@@ -67,6 +96,12 @@ size_t accumulate_workspace_bytes(int64_t N, int64_t d, int64_t M);
 int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                       const int64_t *idx, const double *kw, const double *dist, int64_t M,
                       double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s);
+// the same with the sample kernel computed on the fly (kw_i = 1 - sqrt(1 - exp(-gamma dist_i^2)),
+// the arithmetic of dbgsom_exp_similarity) and the status flag also left as a float64 behind the
+// sums (sums[M (d + 3)]: it rides in the all-reduce buffer): two launches less per epoch
+int launch_accumulate_epoch(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
+                            const int64_t *idx, double gamma, const double *dist, int64_t M,
+                            double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s);
 size_t bucket_sort_workspace_bytes(int64_t N, int64_t M);
 int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order, void *ws,
                        hipStream_t s);

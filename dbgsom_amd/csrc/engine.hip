@@ -36,6 +36,16 @@ struct DevBuf {
         cap = want;
         return DBGSOM_OK;
     }
+    // (re)allocations come zero-filled: the "last workgroup" tickets at the front of the filter
+    // workspace must be 0 before their first use (they reset themselves afterwards)
+    int reserve_zeroed(size_t bytes, hipStream_t s) {
+        if (bytes <= cap) return DBGSOM_OK;
+        const int rc = reserve(bytes);
+        if (rc != DBGSOM_OK) return rc;
+        hipError_t e = hipMemsetAsync(p, 0, cap, s);
+        if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return DBGSOM_EHIP; }
+        return DBGSOM_OK;
+    }
     // grow and keep the first `keep` bytes (ordered on `s`)
     int reserve_keep(size_t bytes, size_t keep, hipStream_t s) {
         if (bytes <= cap) return DBGSOM_OK;
@@ -355,7 +365,7 @@ int stage_weights(dbgsom_ctx *c, const double *W_host, int64_t M, int64_t d, int
 int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t M, int round_f32,
                  const int64_t *prev_idx, const int32_t *order, int64_t *idx, double *dist) {
     TRY(ensure_planes(c, s));
-    TRY(ws.reserve(dbgsom_bmu_filtered_workspace_bytes(s.N, s.dp, M)));
+    TRY(ws.reserve_zeroed(dbgsom_bmu_filtered_workspace_bytes(s.N, s.dp, M), c->stream));
     c->planes_used = planes_for_call(c);
     TRY(dbgsom_bmu_filtered(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), s.planes.p, W, M,
                             c->ww.as<double>(), prev_idx, order, c->seed_stride, c->planes_used, round_f32, idx,
@@ -459,8 +469,10 @@ int epoch_bmu(dbgsom_ctx *c, int64_t M, int round_f32) {
     return DBGSOM_OK;
 }
 
-// sums = [S | K | a | E | status] of the resident samples for winners idx / weights kw / distances dist
-int accumulate_and_reduce(dbgsom_ctx *c, const int64_t *idx, const double *kw, const double *dist, int64_t M) {
+// sums = [S | K | a | E | status] of the resident samples for winners idx / distances dist and the
+// sample weights kw (kw == nullptr: the sample kernel with `gamma`, computed inside the sums kernel)
+int accumulate_and_reduce(dbgsom_ctx *c, const int64_t *idx, const double *kw, double gamma, const double *dist,
+                          int64_t M) {
     Samples &s = c->xs;
     DBGSOM_REQUIRE(M <= DBGSOM_MAX_PROTOTYPES, "M exceeds DBGSOM_MAX_PROTOTYPES");
     const int64_t count = M * (s.dp + 3);
@@ -469,10 +481,15 @@ int accumulate_and_reduce(dbgsom_ctx *c, const int64_t *idx, const double *kw, c
     TRY(c->scal.reserve(256));
     int32_t *status = reinterpret_cast<int32_t *>(c->scal.as<char>() + 64);
     c->part_valid = false;
-    TRY(launch_accumulate(s.X, s.dtype, s.N, s.dp, s.dp, idx, kw, dist, M, c->sums.as<double>(), status,
-                          c->acc_ws.p, c->acc_ws.cap, c->stream));
-    hipLaunchKernelGGL(status_to_f64_kernel, dim3(1), dim3(1), 0, c->stream, status, c->sums.as<double>() + count);
-    TRY(launch_status("status_to_f64_kernel"));
+    if (kw) {
+        TRY(launch_accumulate(s.X, s.dtype, s.N, s.dp, s.dp, idx, kw, dist, M, c->sums.as<double>(), status,
+                              c->acc_ws.p, c->acc_ws.cap, c->stream));
+        hipLaunchKernelGGL(status_to_f64_kernel, dim3(1), dim3(1), 0, c->stream, status, c->sums.as<double>() + count);
+        TRY(launch_status("status_to_f64_kernel"));
+    } else {
+        TRY(launch_accumulate_epoch(s.X, s.dtype, s.N, s.dp, s.dp, idx, gamma, dist, M, c->sums.as<double>(), status,
+                                    c->acc_ws.p, c->acc_ws.cap, c->stream));
+    }
     c->sumsM = M;
     return run_allreduce(c, c->sums.as<double>(), count + 1);
 }
@@ -873,7 +890,7 @@ int dbgsom_ctx_bmu_query(dbgsom_ctx *c, const void *Xq_host, int x_dtype, int64_
                           filter_shape_ok(s, M);
         if (filt) {
             if ((rc = ensure_planes(c, s))) break;
-            if ((rc = fws.reserve(dbgsom_bmu_filtered_workspace_bytes(Nq, dp, M)))) break;
+            if ((rc = fws.reserve_zeroed(dbgsom_bmu_filtered_workspace_bytes(Nq, dp, M), c->stream))) break;
             const int planes = planes_for_call(c);
             rc = dbgsom_bmu_filtered(s.Xb, s.bdtype, Nq, dp, dp, s.xx.as<double>(), s.planes.p, Wq.as<double>(), M,
                                      wwq.as<double>(), nullptr, nullptr, c->seed_stride, planes, round_f32,
@@ -929,9 +946,7 @@ int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f
         if ((rc = epoch_bmu(c, M, round_f32))) break;
         mark(c, 1);
         const int64_t *idx = c->idx[c->icur].as<int64_t>();
-        if ((rc = c->kw.reserve((size_t)s.N * 8))) break;
-        if ((rc = launch_exp_similarity(c->dist.as<double>(), s.N, gamma, c->kw.as<double>(), c->stream))) break;
-        if ((rc = accumulate_and_reduce(c, idx, c->kw.as<double>(), c->dist.as<double>(), M))) break;
+        if ((rc = accumulate_and_reduce(c, idx, nullptr, gamma, c->dist.as<double>(), M))) break;
         // the next epoch's filter visits the samples bucketed by this epoch's winners: the stable
         // counting sort the accumulate step just did (first N int32 of its workspace)
         c->hint_valid = true;
@@ -970,7 +985,7 @@ int dbgsom_ctx_update(dbgsom_ctx *c, const double *W_host, int64_t M, const int6
         if (e != hipSuccess) { set_error("H2D copy failed: %s", hipGetErrorString(e)); rc = DBGSOM_EHIP; break; }
         c->last_filtered = false;
         c->last_idx_valid = true;
-        if ((rc = accumulate_and_reduce(c, idx, c->kw.as<double>(), c->dist.as<double>(), M))) break;
+        if ((rc = accumulate_and_reduce(c, idx, c->kw.as<double>(), 0.0, c->dist.as<double>(), M))) break;
         rc = smooth_and_fetch(c, M, sigma, layout, 0, W_new_host, change_total_host, errors_host, activations_host, idx,
                               nullptr, nullptr);
     } while (0);

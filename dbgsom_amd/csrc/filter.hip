@@ -124,8 +124,12 @@ __global__ __launch_bounds__(256) void tile_partial_kernel(const double *__restr
     }
 }
 
-__global__ __launch_bounds__(64) void tile_score_kernel(const double *__restrict__ part, int M, int dpad,
-                                                        double *__restrict__ score) {
+// score[kt] per k-tile, then -- in the workgroup that finishes last -- kt_sel[0 .. nkt_used) = the
+// nkt_used best tiles, ascending (ties: lower tile first); one wavefront per tile
+__global__ __launch_bounds__(64) void tile_score_select_kernel(const double *__restrict__ part, int M, int dpad,
+                                                               double *__restrict__ score, int nkt,
+                                                               int nkt_used, int32_t *__restrict__ kt_sel,
+                                                               uint32_t *__restrict__ ticket) {
     const int kt = blockIdx.x, k = kt * FKT + threadIdx.x;
     double a = 0.0, b = 0.0;
     for (int rb = 0; rb < TS_RB; ++rb) {
@@ -136,11 +140,7 @@ __global__ __launch_bounds__(64) void tile_score_kernel(const double *__restrict
     var = var > 0.0 ? var : 0.0;
     for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
     if (threadIdx.x == 0) score[kt] = var;
-}
-
-// kt_sel[0 .. nkt_used) = the nkt_used best tiles, ascending (ties: lower tile first); one wavefront
-__global__ __launch_bounds__(64) void tile_select_kernel(const double *__restrict__ score, int nkt,
-                                                         int nkt_used, int32_t *__restrict__ kt_sel) {
+    if (!last_workgroup_done(ticket, (uint32_t)nkt)) return;
     __shared__ int taken[SW_MAX_KT];
     const int lane = threadIdx.x;
     for (int t = lane; t < nkt; t += 64) taken[t] = 0;
@@ -165,24 +165,64 @@ __global__ __launch_bounds__(64) void tile_select_kernel(const double *__restric
     }
 }
 
+// per-prototype tables of the sweep, padded with zeros to Mpad (a multiple of 128) entries:
+// ctab_j = 2 t_j 2^16 / F^2 (so r~ = (xx+yy) - s_i ctab_j T), yypad_j = |w_j|^2;
+// summary[0] = max_j l1_j, summary[1] = max_j t_j, summary[2] = max_j |w_j|^2
+// (ctab_sub, yy_sub: the same for every `stride`-th prototype -- the seed pre-pass;
+//  ictab, yctab: 1 / (ctab tscale) and |w|^2 / (ctab tscale), the form the marking test uses)
+struct WTables {
+    const double *ww;
+    double *ctab, *yypad, *ctab_sub, *yy_sub, *ictab, *yctab, *summary;
+    uint32_t *sched_ctr;
+    double tscale;
+};
+template <int NTHR>
+__device__ __forceinline__ void wtables_body(const double *__restrict__ tw, const double *__restrict__ l1w,
+                                             const double *__restrict__ yy_part, int M, int Mpad, int stride,
+                                             const WTables &o) {
+    __shared__ double r0[NTHR], r1[NTHR], r2[NTHR];
+    const int t = threadIdx.x;
+    if (t < SCHED_CTR) o.sched_ctr[t] = 0u;  // bin counts / cursors / ranges of the exact stage's schedule
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int j = t; j < Mpad; j += NTHR) {
+        const long js = (long)j * stride;  // j-th entry of the strided tables
+        const bool in_sub = js < M;
+        o.ctab_sub[j] = in_sub ? 2.0 * tw[js] * 65536.0 / (FQ * FQ) : 0.0;
+        o.yy_sub[j] = in_sub ? yy_part[j] : 0.0;
+        if (j >= M) { o.ctab[j] = 0.0; o.yypad[j] = 0.0; o.ictab[j] = 0.0; o.yctab[j] = 0.0; continue; }
+        const double cj = 2.0 * tw[j] * 65536.0 / (FQ * FQ);
+        o.ctab[j] = cj;
+        o.yypad[j] = o.ww[j];
+        // the marking test r~ <= thr in the form (xx - thr) / c' + |w|^2 / c' <= s T', c' = c tscale
+        // (T' = T / tscale is what the sweep's accumulators give without the last shift); a
+        // prototype too small for a finite reciprocal is simply always marked
+        const double cs = cj * o.tscale;
+        const bool ok = cs > 1e-280;
+        o.ictab[j] = ok ? 1.0 / cs : 0.0;
+        o.yctab[j] = ok ? o.ww[j] / cs : -INFINITY;
+        a = fmax(a, l1w[j]); b = fmax(b, tw[j]); c = fmax(c, o.ww[j]);
+    }
+    r0[t] = a; r1[t] = b; r2[t] = c;
+    __syncthreads();
+    for (int w = NTHR / 2; w > 0; w >>= 1) {
+        if (t < w) { r0[t] = fmax(r0[t], r0[t + w]); r1[t] = fmax(r1[t], r1[t + w]); r2[t] = fmax(r2[t], r2[t + w]); }
+        __syncthreads();
+    }
+    if (t == 0) { o.summary[0] = r0[0]; o.summary[1] = r1[0]; o.summary[2] = r2[0]; }
+}
+
 // The prototypes' digit planes in the order the sweep's DMA wants them: int8 [3][dpad / 64][rows_pad]
 // [64], i.e. k-tile-major, so that the 64-byte pieces of 16 consecutive rows are ONE contiguous
 // KiB (whole 128-byte lines per DMA instruction instead of 16 half lines), with the 16-byte
 // chunks of a piece already XOR-swizzled by (row >> 2) & 3 the way the LDS image is read.
 // wt: all M prototypes (rows_pad = Mpad); wt_sub: every `stride`-th (rows_pad = Msubpad), the
 // seed pre-pass.  Pad rows are never initialised: the sweep masks j >= M.
-__global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__restrict__ W, int M, int d,
-                                                            int dpad, int Mpad, int stride,
-                                                            int Msubpad, int nkt_used,
-                                                            const int32_t *__restrict__ kt_sel,
-                                                            int8_t *__restrict__ wt,
-                                                            int8_t *__restrict__ wt_sub,
-                                                            double *__restrict__ scale,
-                                                            double *__restrict__ l1,
-                                                            double *__restrict__ yy_part) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+__device__ __forceinline__ void slice_w_row(const double *__restrict__ W, int M, int d, int dpad, int Mpad,
+                                            int stride, int Msubpad, int nkt_used,
+                                            const int32_t *__restrict__ kt_sel, int8_t *__restrict__ wt,
+                                            int8_t *__restrict__ wt_sub, double *__restrict__ scale,
+                                            double *__restrict__ l1, double *__restrict__ yy_part, int row,
+                                            int lane) {
     const double *a = W + (size_t)row * d;
     double m = 0.0, s1 = 0.0;
     for (int k = lane; k < d; k += 64) {
@@ -229,54 +269,26 @@ __global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__rest
     }
 }
 
-// per-prototype tables of the sweep, padded with zeros to Mpad (a multiple of 128) entries:
-// ctab_j = 2 t_j 2^16 / F^2 (so r~ = (xx+yy) - s_i ctab_j T), yypad_j = |w_j|^2;
-// summary[0] = max_j l1_j, summary[1] = max_j t_j, summary[2] = max_j |w_j|^2
-// (ctab_sub, yy_sub: the same for every `stride`-th prototype -- the seed pre-pass;
-//  ictab, yctab: 1 / (ctab tscale) and |w|^2 / (ctab tscale), the form the marking test uses)
-__global__ __launch_bounds__(1024) void wtables_kernel(const double *__restrict__ tw,
-                                                       const double *__restrict__ l1w,
-                                                       const double *__restrict__ ww,
-                                                       const double *__restrict__ yy_part, int M,
-                                                       int Mpad, int stride,
-                                                       double *__restrict__ ctab,
-                                                       double *__restrict__ yypad,
-                                                       double *__restrict__ ctab_sub,
-                                                       double *__restrict__ yy_sub,
-                                                       double tscale, double *__restrict__ ictab,
-                                                       double *__restrict__ yctab,
-                                                       double *__restrict__ summary,
-                                                       uint32_t *__restrict__ sched_ctr) {
-    __shared__ double r0[1024], r1[1024], r2[1024];
-    const int t = threadIdx.x;
-    if (t < SCHED_CTR) sched_ctr[t] = 0u;  // bin counts / cursors / ranges of the exact stage's schedule
-    double a = 0.0, b = 0.0, c = 0.0;
-    for (int j = t; j < Mpad; j += 1024) {
-        const long js = (long)j * stride;  // j-th entry of the strided tables
-        const bool in_sub = js < M;
-        ctab_sub[j] = in_sub ? 2.0 * tw[js] * 65536.0 / (FQ * FQ) : 0.0;
-        yy_sub[j] = in_sub ? yy_part[j] : 0.0;
-        if (j >= M) { ctab[j] = 0.0; yypad[j] = 0.0; ictab[j] = 0.0; yctab[j] = 0.0; continue; }
-        const double cj = 2.0 * tw[j] * 65536.0 / (FQ * FQ);
-        ctab[j] = cj;
-        yypad[j] = ww[j];
-        // the marking test r~ <= thr in the form (xx - thr) / c' + |w|^2 / c' <= s T', c' = c tscale
-        // (T' = T / tscale is what the sweep's accumulators give without the last shift); a
-        // prototype too small for a finite reciprocal is simply always marked
-        const double cs = cj * tscale;
-        const bool ok = cs > 1e-280;
-        ictab[j] = ok ? 1.0 / cs : 0.0;
-        yctab[j] = ok ? ww[j] / cs : -INFINITY;
-        a = fmax(a, l1w[j]); b = fmax(b, tw[j]); c = fmax(c, ww[j]);
-    }
-    r0[t] = a; r1[t] = b; r2[t] = c;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (t < w) { r0[t] = fmax(r0[t], r0[t + w]); r1[t] = fmax(r1[t], r1[t + w]); r2[t] = fmax(r2[t], r2[t + w]); }
-        __syncthreads();
-    }
-    if (t == 0) { summary[0] = r0[0]; summary[1] = r1[0]; summary[2] = r2[0]; }
+
+__global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__restrict__ W, int M, int d,
+                                                            int dpad, int Mpad, int stride,
+                                                            int Msubpad, int nkt_used,
+                                                            const int32_t *__restrict__ kt_sel,
+                                                            int8_t *__restrict__ wt,
+                                                            int8_t *__restrict__ wt_sub,
+                                                            double *__restrict__ scale,
+                                                            double *__restrict__ l1,
+                                                            double *__restrict__ yy_part,
+                                                            uint32_t *__restrict__ ticket, WTables tables) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < M) slice_w_row(W, M, d, dpad, Mpad, stride, Msubpad, nkt_used, kt_sel, wt, wt_sub, scale, l1, yy_part,
+                             row, lane);
+    // the per-prototype tables of the sweep need every row's scale / l1 / partial norm: the
+    // workgroup that finishes last builds them (one launch less than a kernel of their own)
+    if (last_workgroup_done(ticket, gridDim.x)) wtables_body<256>(scale, l1, yy_part, M, Mpad, stride, tables);
 }
+
 
 // Error bound of r~ for sample i against ANY prototype of this epoch, measured against the value
 // the exact kernel computes (r_chain):
@@ -317,6 +329,14 @@ __device__ __forceinline__ double filter_eps(double s, double l1x, double xx, do
     const double dropped = (double)d * per_k * s * t_max / (FQ * FQ);
     const double rounding = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xx + yy_max);
     return 2.0 * (quant + dropped) * (1.0 + 1e-7) + rounding;
+}
+
+// launch-order bin of a workgroup of the exact stage by the length of its candidate list (section 2b)
+__device__ __forceinline__ int sched_bin(uint32_t c) {
+    if (c <= 16u) return 15;
+    if (c <= 32u) return 14;
+    const int steps = (int)((c + 47u) / 48u);
+    return steps >= 14 ? 0 : 14 - steps;
 }
 
 // ---- 2. the int8 sweep -------------------------------------------------------------------------
@@ -373,7 +393,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount,
     int64_t *__restrict__ seed, int jstride, int w_rows, int nkt_used,
-    const int32_t *__restrict__ kt_sel) {
+    const int32_t *__restrict__ kt_sel, uint32_t *__restrict__ sched_ctr) {
     using L = SweepLds<PLANES, JT>;
     constexpr int NPL = PLANES, NLV = PLANES, BJ = L::BJ;
     constexpr int DMA_TILE = NPL * (1 + JT);  // DMA instructions per wave per tile
@@ -946,7 +966,10 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             }
             base += __shfl(pre, 63, 64);
         }
-        if (lane == 0) ucount[blockIdx.x] = base;
+        if (lane == 0) {
+            ucount[blockIdx.x] = base;
+            atomicAdd(&sched_ctr[sched_bin(base)], 1u);  // bin counts of the exact stage's schedule (2b)
+        }
 #if SWEEP_EXPERIMENT & 512
         if (lane == 0) reinterpret_cast<unsigned *>(out + 512)[0] = (unsigned)misc[3];
 #endif
@@ -1002,7 +1025,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
     const double *__restrict__ craw, const double *__restrict__ summary, int M,
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, int w_rows,
-    int64_t *__restrict__ seed, int jstride, int nkt_used, const int32_t *__restrict__ kt_sel) {
+    int64_t *__restrict__ seed, int jstride, int nkt_used, const int32_t *__restrict__ kt_sel,
+    uint32_t *__restrict__ sched_ctr) {
     using L = Sweep4Lds;
     // NW wavefronts as 2 (samples) x WJ (prototypes), wavefront tile 64 x 32 JT: 4 -> 64 x 128,
     // 8 -> 64 x 64 (64 accumulator registers: <= 128 VGPRs, four wavefronts per SIMD)
@@ -1446,7 +1470,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
             }
             base += __shfl(pre, 63, 64);
         }
-        if (lane == 0) ucount[blockIdx.x] = base;
+        if (lane == 0) {
+            ucount[blockIdx.x] = base;
+            atomicAdd(&sched_ctr[sched_bin(base)], 1u);  // bin counts of the exact stage's schedule (2b)
+        }
 #if SWEEP_EXPERIMENT & 1024
         {   // stamps of the four waves behind the list: uint32 at uint16 offset 512 of this row
             unsigned *dbg = reinterpret_cast<unsigned *>(out + 512);
@@ -1464,22 +1491,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
 // (bins 0 .. 13), then class 2 (14), then class 1 (15) -- and every class kernel walks its range of
 // that schedule.  Within a bin the order is whatever the atomics give (blocks of 256 consecutive
 // workgroups stay together): the schedule only decides WHEN a workgroup runs, never what it writes.
-__device__ __forceinline__ int sched_bin(uint32_t c) {
-    if (c <= 16u) return 15;
-    if (c <= 32u) return 14;
-    const int steps = (int)((c + 47u) / 48u);
-    return steps >= 14 ? 0 : 14 - steps;
-}
-__global__ __launch_bounds__(256) void sched_count_kernel(const uint32_t *__restrict__ ucount, int nb,
-                                                          uint32_t *__restrict__ ctr) {
-    __shared__ uint32_t h[SCHED_BINS];
-    if (threadIdx.x < SCHED_BINS) h[threadIdx.x] = 0u;
-    __syncthreads();
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b < nb) atomicAdd(&h[sched_bin(ucount[b])], 1u);
-    __syncthreads();
-    if (threadIdx.x < SCHED_BINS && h[threadIdx.x]) atomicAdd(&ctr[threadIdx.x], h[threadIdx.x]);
-}
 __global__ __launch_bounds__(256) void sched_fill_kernel(const uint32_t *__restrict__ ucount, int nb,
                                                          uint32_t *__restrict__ ctr,
                                                          int32_t *__restrict__ sched) {
@@ -1802,6 +1813,8 @@ static size_t carve_planes(PlaneBuf *b, char *base, int64_t rows, int64_t d) {
 }
 
 struct FilterWs {
+    uint32_t *tickets;     // [0] tile score/select, [1] slice W/tables: "last workgroup" tickets (offset 0 of
+                           // the workspace whatever its shape; 0 between launches, see last_workgroup_done)
     int8_t *wt, *wt_sub;   // k-tile-major digit planes of the prototypes / of the pre-pass subset
     double *wscale, *wl1;  // M each
     double *ctab, *yypad, *ctab_sub, *yy_sub, *ictab, *yctab, *yy_part, *summary;
@@ -1821,6 +1834,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const int64_t Mpad = (M + 511) / 512 * 512, nb = (N + 127) / 128, dpad = filter_dpad(d);  // whole 512-prototype chunks
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t otk = take(256);
     const size_t ow = take((size_t)3 * Mpad * dpad), ows = take((size_t)3 * Mpad * dpad);
     const size_t osc = take((size_t)M * 8), ol1 = take((size_t)M * 8);
     const size_t o0 = take((size_t)Mpad * 8), o1 = take((size_t)Mpad * 8), o2 = take(64);
@@ -1833,6 +1847,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
     const size_t o16 = take((size_t)nb * 4), o17 = take((size_t)SCHED_CTR * 4);
     if (f) {
+        f->tickets = (uint32_t *)(base + otk);
         f->sched = (int32_t *)(base + o16); f->sched_ctr = (uint32_t *)(base + o17);
         f->wt = (int8_t *)(base + ow); f->wt_sub = (int8_t *)(base + ows);
         f->wscale = (double *)(base + osc); f->wl1 = (double *)(base + ol1);
@@ -1883,8 +1898,8 @@ thread_local StageTimer g_timer;
 // a second stream for launches that may overlap (per thread, created on first use; if it cannot be
 // created the work simply stays on the caller's stream)
 struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t forked = nullptr, joined = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t forked = nullptr, joined = nullptr, joined2 = nullptr;
     int state = 0;  // 0 untried, 1 ready, -1 unavailable
     int device = -1;
     bool ready() {
@@ -1893,8 +1908,10 @@ struct SideStream {
         if (state == 0) {
             device = dev;
             state = (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+                     hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking) == hipSuccess &&
                      hipEventCreateWithFlags(&forked, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
+                     hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&joined2, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
         }
         return state == 1 && dev == device;  // a thread that moved to another device: no fork
     }
@@ -2025,18 +2042,17 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     if (nkt_used < nkt_full) {
         hipLaunchKernelGGL(tile_partial_kernel, dim3((unsigned)nkt_full, TS_RB), dim3(256), 0, s, W_dev,
                            (int)M, (int)d, dpad, f.tile_part);
-        hipLaunchKernelGGL(tile_score_kernel, dim3((unsigned)nkt_full), dim3(64), 0, s, f.tile_part, (int)M,
-                           dpad, f.tile_score);
-        hipLaunchKernelGGL(tile_select_kernel, dim3(1), dim3(64), 0, s, f.tile_score, nkt_full, nkt_used,
-                           f.kt_sel);
+        hipLaunchKernelGGL(tile_score_select_kernel, dim3((unsigned)nkt_full), dim3(64), 0, s, f.tile_part, (int)M,
+                           dpad, f.tile_score, nkt_full, nkt_used, f.kt_sel, f.tickets + 0);
     }
+    WTables tables;
+    tables.ww = ww_dev; tables.ctab = f.ctab; tables.yypad = f.yypad; tables.ctab_sub = f.ctab_sub;
+    tables.yy_sub = f.yy_sub; tables.ictab = f.ictab; tables.yctab = f.yctab; tables.summary = f.summary;
+    tables.sched_ctr = f.sched_ctr; tables.tscale = sweep_tscale(sweep_planes);
     hipLaunchKernelGGL(slice_w_tiled_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, W_dev,
                        (int)M, (int)d, dpad, (int)f.Mpad, seed_stride, Msubpad, nkt_used,
                        nkt_used < nkt_full ? f.kt_sel : (const int32_t *)nullptr, f.wt,
-                       f.wt_sub, f.wscale, f.wl1, f.yy_part);
-    hipLaunchKernelGGL(wtables_kernel, dim3(1), dim3(1024), 0, s, f.wscale, f.wl1, ww_dev, f.yy_part, (int)M,
-                       (int)f.Mpad, seed_stride, f.ctab, f.yypad, f.ctab_sub, f.yy_sub,
-                       sweep_tscale(sweep_planes), f.ictab, f.yctab, f.summary, f.sched_ctr);
+                       f.wt_sub, f.wscale, f.wl1, f.yy_part, f.tickets + 1, tables);
     g_timer.mark(1, s);
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
@@ -2051,17 +2067,17 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
             S4_LAUNCH(1, f.nb, xb.planes, xb.scale,
                                xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub, f.yy_sub,
                                f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
-                               f.ulist, (int)f.Mpad, f.ucount, Msubpad, f.seed, seed_stride, nkt_used, f.kt_sel);
+                               f.ulist, (int)f.Mpad, f.ucount, Msubpad, f.seed, seed_stride, nkt_used, f.kt_sel, f.sched_ctr);
         else if (sweep_planes == 1)
             hipLaunchKernelGGL((sweep_i8_kernel<1, 1, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub,
                            f.yy_sub, f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
-                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad, nkt_used, f.kt_sel);
+                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad, nkt_used, f.kt_sel, f.sched_ctr);
         else
             hipLaunchKernelGGL((sweep_i8_kernel<1, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub,
                            f.yy_sub, f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
-                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad, nkt_used, f.kt_sel);
+                           f.ulist, (int)f.Mpad, f.ucount, f.seed, seed_stride, Msubpad, nkt_used, f.kt_sel, f.sched_ctr);
         g_timer.mark(2, s);
         const int rc = launch_bucket_sort(f.seed, N, M, f.order, f.sort_ws, s);
         if (rc != DBGSOM_OK) return rc;
@@ -2075,7 +2091,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     hipLaunchKernelGGL((sweep_i8_kernel<0, P, J>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,   \
                        xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab, f.yypad,    \
                        f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad,     \
-                       f.ucount, (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr)
+                       f.ucount, (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr, f.sched_ctr)
     // one digit product: 4-wavefront workgroups unless DBGSOM_SWEEP_SHAPE=8 (see dbgsom_sweep_shape)
     const int sweep_shape = dbgsom_sweep_shape(M, d);
     if (sweep_planes == 1 && sweep_shape == 4 && order_dev && M <= Sweep4Lds::MAX_M) {
@@ -2083,22 +2099,21 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         S4_LAUNCH(0, f.nb, xb.planes, xb.scale,
                            xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab, f.yypad, f.ctab,
                            f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int)f.Mpad, (int64_t *)nullptr, 1, 0, (const int32_t *)nullptr);
+                           (int)f.Mpad, (int64_t *)nullptr, 1, 0, (const int32_t *)nullptr, f.sched_ctr);
     } else if (sweep_planes == 1) {  // one digit product: 128 x 512 tile (128 x 256 for small maps)
         if (M > 256) DBGSOM_SWEEP(1, 4); else DBGSOM_SWEEP(1, 2);
     } else if (sweep_planes == 3)
         hipLaunchKernelGGL((sweep_i8_kernel<0, 3, 1>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab,
                            f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr);
+                           (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr, f.sched_ctr);
     else
         hipLaunchKernelGGL((sweep_i8_kernel<0, 2, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab,
                            f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr);
+                           (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr, f.sched_ctr);
     g_timer.mark(4, s);
-    hipLaunchKernelGGL(sched_count_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount,
-                       (int)f.nb, f.sched_ctr);
+    // (the bin counts were added up by the sweep's workgroups as they wrote their list lengths)
     hipLaunchKernelGGL(sched_fill_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount,
                        (int)f.nb, f.sched_ctr, f.sched);
     // the three list-length classes write disjoint samples: they run side by side (classes 1 and 2
@@ -2106,10 +2121,11 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     // lists on a mostly idle chip -- overlaps the others
     SideStream &side = g_side;
     const bool fork = side.ready();
-    hipStream_t s2 = fork ? side.stream : s;
+    hipStream_t s2 = fork ? side.stream : s, s3 = fork ? side.stream2 : s;
     if (fork) {
         DBGSOM_HIP_CHECK(hipEventRecord(side.forked, s));
         DBGSOM_HIP_CHECK(hipStreamWaitEvent(s2, side.forked, 0));
+        DBGSOM_HIP_CHECK(hipStreamWaitEvent(s3, side.forked, 0));
     }
 #define DBGSOM_SUBSET_W(JTL, NWV_, STREAM)                                                        \
     do {                                                                                          \
@@ -2139,14 +2155,16 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     } while (0)
     DBGSOM_SUBSET(3, s);
     DBGSOM_SUBSET(2, s2);
-    DBGSOM_SUBSET(1, s2);
+    DBGSOM_SUBSET(1, s3);
 #undef DBGSOM_SUBSET
 #undef DBGSOM_SUBSET_W
 #undef DBGSOM_SWEEP
 #undef S4_LAUNCH
     if (fork) {
         DBGSOM_HIP_CHECK(hipEventRecord(side.joined, s2));
+        DBGSOM_HIP_CHECK(hipEventRecord(side.joined2, s3));
         DBGSOM_HIP_CHECK(hipStreamWaitEvent(s, side.joined, 0));
+        DBGSOM_HIP_CHECK(hipStreamWaitEvent(s, side.joined2, 0));
     }
     g_timer.mark(5, s);
     g_timer.valid = g_timer.enabled;

@@ -18,7 +18,7 @@ struct SmoothWs {
     double *G;      // M x M   h * a^T
     double *den;    // M
     double *rowchg; // M
-    int32_t *rank;  // M       rank among non-empty neurons
+    uint32_t *ticket;  // "last workgroup" ticket of the row-change kernel
     double *part;   // splits x M x d   partial products of the split-K GEMM (splits > 1)
 };
 
@@ -45,7 +45,7 @@ static size_t carve_smooth(SmoothWs *w, char *base, int64_t M, int64_t d) {
         w->part = (double *)(base + oP);
         w->C = (double *)(base + oC); w->G = (double *)(base + oG);
         w->den = (double *)(base + oD); w->rowchg = (double *)(base + oR);
-        w->rank = (int32_t *)(base + oK);
+        w->ticket = (uint32_t *)(base + oK);
     }
     return off;
 }
@@ -55,46 +55,49 @@ size_t smooth_workspace_bytes(int64_t M, int64_t d) {
     return carve_smooth(nullptr, nullptr, M, d);
 }
 
-// rank[j] = number of non-empty neurons before j (one workgroup, ordered)
-__global__ __launch_bounds__(1024) void rank_kernel(const double *__restrict__ a, int M,
-                                                    int32_t *__restrict__ rank) {
-    __shared__ int32_t part[1024];
-    const int t = threadIdx.x;
-    const int per = (M + 1023) / 1024;
-    const int lo = t * per, hi = min(M, lo + per);
-    int32_t c = 0;
-    for (int j = lo; j < hi; ++j) c += (a[j] > 0.0);
-    part[t] = c;
-    __syncthreads();
-    if (t == 0) {
-        int32_t run = 0;
-        for (int u = 0; u < 1024; ++u) { const int32_t v = part[u]; part[u] = run; run += v; }
-    }
-    __syncthreads();
-    c = part[t];
-    for (int j = lo; j < hi; ++j) { rank[j] = c; c += (a[j] > 0.0); }
-}
-
-// C[dst(j), :] = S[j, :] / K[j] for non-empty j; C was zero-filled beforehand
-__global__ void centres_kernel(const double *__restrict__ S, const double *__restrict__ K,
-                               const double *__restrict__ a, const int32_t *__restrict__ rank,
-                               int M, int d, int layout, double *__restrict__ C) {
-    const int j = blockIdx.x;
-    if (!(a[j] > 0.0)) return;
-    const int dst = (layout == DBGSOM_CENTRES_COMPACT) ? rank[j] : j;
-    const double k = K[j];
-    for (int c = threadIdx.x; c < d; c += blockDim.x)
-        C[(size_t)dst * d + c] = S[(size_t)j * d + c] / k;
-}
-
-// G[i, j] = exp(-(hop^2 / (2 sigma^2))) * a_j ; den[i] = sum_j G[i, j] (fixed tree order)
-__global__ __launch_bounds__(256) void neighbourhood_kernel(const float *__restrict__ hop,
-                                                            const double *__restrict__ a, int M,
-                                                            double two_sigma_sq,
-                                                            double *__restrict__ G,
-                                                            double *__restrict__ den) {
+// One launch prepares both GEMM operands (it used to be a memset and three kernels):
+//   workgroup j < M:  row j of the centres -- C[dst(j), :] = S[j, :] / K[j] for a non-empty neuron,
+//                     dst = rank among the non-empty neurons (COMPACT, quirk Q1) or j (ALIGNED);
+//                     the rows nobody writes (COMPACT: the last M - #non-empty; ALIGNED: the empty
+//                     neurons') are zero-filled by the workgroup of the same number;
+//                     row j of G = exp(-(hop^2 / (2 sigma^2))) * a and den[j] = its sum (fixed tree).
+// The rank of a neuron is a count over a[0 .. j): every workgroup counts for itself (M reads).
+__global__ __launch_bounds__(256) void smooth_prep_kernel(const double *__restrict__ S,
+                                                          const double *__restrict__ K,
+                                                          const double *__restrict__ a,
+                                                          const float *__restrict__ hop, int M, int d,
+                                                          int layout, double two_sigma_sq,
+                                                          double *__restrict__ C, double *__restrict__ G,
+                                                          double *__restrict__ den,
+                                                          uint32_t *__restrict__ ticket) {
     __shared__ double red[256];
+    __shared__ int cnt[256], cnt_all[256];
     const int i = blockIdx.x, t = threadIdx.x;
+    if (i == 0 && t == 0) *ticket = 0u;  // of the row-change kernel behind the GEMM
+    // non-empty neurons before i, and in all
+    int before = 0, all = 0;
+    for (int j = t; j < M; j += 256) {
+        const int ne = a[j] > 0.0;
+        all += ne;
+        before += (j < i) ? ne : 0;
+    }
+    cnt[t] = before;
+    cnt_all[t] = all;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) { cnt[t] += cnt[t + w]; cnt_all[t] += cnt_all[t + w]; }
+        __syncthreads();
+    }
+    const int rank = cnt[0], nne = cnt_all[0];
+    const bool alive = a[i] > 0.0;
+    if (alive) {
+        const int dst = (layout == DBGSOM_CENTRES_COMPACT) ? rank : i;
+        const double k = K[i];
+        for (int c = t; c < d; c += 256) C[(size_t)dst * d + c] = S[(size_t)i * d + c] / k;
+    }
+    const bool zero_row = (layout == DBGSOM_CENTRES_COMPACT) ? (i >= nne) : !alive;
+    if (zero_row)
+        for (int c = t; c < d; c += 256) C[(size_t)i * d + c] = 0.0;
     double s = 0.0;
     for (int j = t; j < M; j += 256) {
         const double h = (double)hop[(size_t)i * M + j];
@@ -203,7 +206,9 @@ __global__ __launch_bounds__(256) void rowchange_kernel(const double *__restrict
                                                         double *__restrict__ Wn, int M, int d,
                                                         int splits, const double *__restrict__ part,
                                                         const double *__restrict__ den,
-                                                        double *__restrict__ rowchg) {
+                                                        double *__restrict__ rowchg,
+                                                        uint32_t *__restrict__ ticket,
+                                                        double *__restrict__ change_total) {
     __shared__ double red[256];
     const int i = blockIdx.x, t = threadIdx.x;
     double s = 0.0;
@@ -228,21 +233,24 @@ __global__ __launch_bounds__(256) void rowchange_kernel(const double *__restrict
         __syncthreads();
     }
     if (t == 0) rowchg[i] = sqrt(red[0]);
-}
-
-__global__ __launch_bounds__(1024) void total_kernel(const double *__restrict__ v, int M,
-                                                     double *__restrict__ out) {
-    __shared__ double red[1024];
-    const int t = threadIdx.x;
-    double s = 0.0;
-    for (int j = t; j < M; j += 1024) s += v[j];
-    red[t] = s;
+    // change_total = sum_i rowchg[i]: the workgroup that finishes last adds them up, in the fixed
+    // order of a 1024-leaf strided binary tree -- bitwise reproducible
+    if (!last_workgroup_done(ticket, gridDim.x)) return;
+    __shared__ double tot[256];
+    double p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        double v = 0.0;
+        for (int j = t + 256 * u; j < M; j += 1024) v += rowchg[j];
+        p[u] = v;
+    }
+    tot[t] = (p[0] + p[2]) + (p[1] + p[3]);   // tree levels 512 and 256 of the 1024-leaf tree
     __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (t < w) red[t] += red[t + w];
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) tot[t] += tot[t + w];
         __syncthreads();
     }
-    if (t == 0) out[0] = red[0];
+    if (t == 0) change_total[0] = tot[0];
 }
 
 int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, double sigma,
@@ -264,19 +272,14 @@ int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, do
     carve_smooth(&w, (char *)ws, M, d);
     const int Mi = (int)M, di = (int)d;
     const double *S = sums, *K = sums + (size_t)M * d, *a = K + M;
-    DBGSOM_HIP_CHECK(hipMemsetAsync(w.C, 0, (size_t)M * d * 8, s));
-    hipLaunchKernelGGL(rank_kernel, dim3(1), dim3(1024), 0, s, a, Mi, w.rank);
-    hipLaunchKernelGGL(centres_kernel, dim3((unsigned)M), dim3(256), 0, s, S, K, a, w.rank, Mi, di,
-                       layout, w.C);
-    hipLaunchKernelGGL(neighbourhood_kernel, dim3((unsigned)M), dim3(256), 0, s, hop, a, Mi,
-                       2.0 * (sigma * sigma), w.G, w.den);
+    hipLaunchKernelGGL(smooth_prep_kernel, dim3((unsigned)M), dim3(256), 0, s, S, K, a, hop, Mi, di, layout,
+                       2.0 * (sigma * sigma), w.C, w.G, w.den, w.ticket);
     const int splits = gemm_splits(M, d);
     dim3 grid((unsigned)((d + GT - 1) / GT), (unsigned)((M + GT - 1) / GT), (unsigned)splits);
     hipLaunchKernelGGL(smooth_gemm_kernel, grid, dim3(256), 0, s, w.G, w.C, w.den, Mi, di, splits,
                        w.part, W_new);
     hipLaunchKernelGGL(rowchange_kernel, dim3((unsigned)M), dim3(256), 0, s, W_old, W_new, Mi, di,
-                       splits, w.part, w.den, w.rowchg);
-    hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1024), 0, s, w.rowchg, Mi, change_total);
+                       splits, w.part, w.den, w.rowchg, w.ticket, change_total);
     return launch_status("smooth kernels");
 }
 

@@ -136,6 +136,8 @@ int dbgsom_smooth(const double *sums_dev, int64_t M, int64_t d, const float *hop
 size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d);
 int dbgsom_filter_prepare(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                           void *planes_dev, size_t planes_bytes, void *stream);
+/* The workspace of dbgsom_bmu_filtered must be zero-filled ONCE after it is allocated (its first 256
+ * bytes hold self-resetting "last workgroup" tickets); calls leave it ready for the next call. */
 size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M);
 int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                         const double *xx_dev, const void *xplanes_dev, const double *W_dev,
