@@ -170,8 +170,17 @@ __global__ __launch_bounds__(64) void tile_score_select_kernel(const double *__r
 // summary[0] = max_j l1_j, summary[1] = max_j t_j, summary[2] = max_j |w_j|^2
 // (ctab_sub, yy_sub: the same for every `stride`-th prototype -- the seed pre-pass;
 //  ictab, yctab: 1 / (ctab tscale) and |w|^2 / (ctab tscale), the form the marking test uses)
+// float32 image of a table entry for the float32 chunk epilogue: exact up to a relative 2^-24 when
+// the value is a normal float32 (or 0); anything else has no bounded relative error and the entry
+// is made "always marked" by the caller
+__device__ __forceinline__ bool f32_representable(double v) {
+    const double a = fabs(v);
+    return v == 0.0 || (a >= 1.1754943508222875e-38 && a <= 3.4028234663852886e+38);
+}
+
 struct WTables {
     const double *ww;
+    float *tab32, *chk32;
     double *ctab, *yypad, *ctab_sub, *yy_sub, *ictab, *yctab, *summary;
     uint32_t *sched_ctr;
     double tscale;
@@ -187,9 +196,17 @@ __device__ __forceinline__ void wtables_body(const double *__restrict__ tw, cons
     for (int j = t; j < Mpad; j += NTHR) {
         const long js = (long)j * stride;  // j-th entry of the strided tables
         const bool in_sub = js < M;
-        o.ctab_sub[j] = in_sub ? 2.0 * tw[js] * 65536.0 / (FQ * FQ) : 0.0;
+        const double csub = in_sub ? 2.0 * tw[js] * 65536.0 / (FQ * FQ) : 0.0;
+        o.ctab_sub[j] = csub;
         o.yy_sub[j] = in_sub ? yy_part[j] : 0.0;
-        if (j >= M) { o.ctab[j] = 0.0; o.yypad[j] = 0.0; o.ictab[j] = 0.0; o.yctab[j] = 0.0; continue; }
+        // (the seed pre-pass only needs SOME seed: plain float32, no guard)
+        o.tab32[2 * (size_t)Mpad + j] = in_sub ? (float)yy_part[j] : 0.f;
+        o.tab32[3 * (size_t)Mpad + j] = (float)(csub * 65536.0);
+        if (j >= M) {
+            o.ctab[j] = 0.0; o.yypad[j] = 0.0; o.ictab[j] = 0.0; o.yctab[j] = 0.0;
+            o.tab32[j] = 0.f; o.tab32[(size_t)Mpad + j] = 0.f;
+            continue;
+        }
         const double cj = 2.0 * tw[j] * 65536.0 / (FQ * FQ);
         o.ctab[j] = cj;
         o.yypad[j] = o.ww[j];
@@ -200,6 +217,9 @@ __device__ __forceinline__ void wtables_body(const double *__restrict__ tw, cons
         const bool ok = cs > 1e-280;
         o.ictab[j] = ok ? 1.0 / cs : 0.0;
         o.yctab[j] = ok ? o.ww[j] / cs : -INFINITY;
+        const bool ok32 = ok && f32_representable(1.0 / cs) && f32_representable(o.ww[j] / cs);
+        o.tab32[j] = ok32 ? (float)(o.ww[j] / cs) : -INFINITY;
+        o.tab32[(size_t)Mpad + j] = ok32 ? (float)(1.0 / cs) : 0.f;
         a = fmax(a, l1w[j]); b = fmax(b, tw[j]); c = fmax(c, o.ww[j]);
     }
     r0[t] = a; r1[t] = b; r2[t] = c;
@@ -209,6 +229,32 @@ __device__ __forceinline__ void wtables_body(const double *__restrict__ tw, cons
         __syncthreads();
     }
     if (t == 0) { o.summary[0] = r0[0]; o.summary[1] = r1[0]; o.summary[2] = r2[0]; }
+    // per 256-prototype chunk: the smallest |w|^2 / c' and the smallest / largest 1 / c' of its float32
+    // table entries -- the coarse integer test of the two-per-CU sweep's epilogue (a lower bound of
+    // the per-pair threshold over the whole chunk).  Round u of the loop above handled chunk u, one
+    // entry per thread (NTHR == 256): wavefront reduction, then the four wavefronts' results.
+    static_assert(NTHR == 256, "one chunk of 256 table entries per round");
+    __shared__ float cst[64][4][3];
+    __syncthreads();   // this workgroup's table entries are visible to it
+    for (int ch = 0; ch < Mpad / 256; ++ch) {
+        const int j = ch * 256 + t;
+        float ymin = INFINITY, cmin = INFINITY, cmax = -INFINITY;
+        if (j < M) { ymin = o.tab32[j]; cmin = cmax = o.tab32[(size_t)Mpad + j]; }
+        for (int off = 32; off > 0; off >>= 1) {
+            ymin = fminf(ymin, __shfl_xor(ymin, off, 64));
+            cmin = fminf(cmin, __shfl_xor(cmin, off, 64));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, off, 64));
+        }
+        if ((t & 63) == 0 && ch < 64) { cst[ch][t >> 6][0] = ymin; cst[ch][t >> 6][1] = cmin; cst[ch][t >> 6][2] = cmax; }
+    }
+    __syncthreads();
+    if (t < Mpad / 256 && t < 64) {
+        float ymin = cst[t][0][0], cmin = cst[t][0][1], cmax = cst[t][0][2];
+        for (int w = 1; w < 4; ++w) {
+            ymin = fminf(ymin, cst[t][w][0]); cmin = fminf(cmin, cst[t][w][1]); cmax = fmaxf(cmax, cst[t][w][2]);
+        }
+        o.chk32[4 * t + 0] = ymin; o.chk32[4 * t + 1] = cmin; o.chk32[4 * t + 2] = cmax; o.chk32[4 * t + 3] = 0.f;
+    }
 }
 
 // The prototypes' digit planes in the order the sweep's DMA wants them: int8 [3][dpad / 64][rows_pad]
@@ -337,6 +383,12 @@ __device__ __forceinline__ int sched_bin(uint32_t c) {
     if (c <= 32u) return 14;
     const int steps = (int)((c + 47u) / 48u);
     return steps >= 14 ? 0 : 14 - steps;
+}
+
+// extra slack of thr_i for the float32 chunk epilogue of the two-per-CU sweep (derivation there):
+// 2.5e-7 >= 4 2^-24 / (1 - 4 2^-24); the |A_i| part is applied where A_i is converted
+__device__ __forceinline__ double epilogue32_slack(double xx, double yy_max) {
+    return 2.5e-7 * (xx + 2.1 * yy_max);
 }
 
 // ---- 2. the int8 sweep -------------------------------------------------------------------------
@@ -1020,13 +1072,13 @@ template <int MODE, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: the second figure is waves per SIMD)
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx,
     const double *__restrict__ l1x, const double *__restrict__ xx, int64_t N, int d, int dpad,
-    const int8_t *__restrict__ wplanes, const double *__restrict__ ytab_g,
-    const double *__restrict__ ctab_g, const double *__restrict__ yraw,
+    const int8_t *__restrict__ wplanes, const float *__restrict__ ytab_g,
+    const float *__restrict__ ctab_g, const double *__restrict__ yraw,
     const double *__restrict__ craw, const double *__restrict__ summary, int M,
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, int w_rows,
     int64_t *__restrict__ seed, int jstride, int nkt_used, const int32_t *__restrict__ kt_sel,
-    uint32_t *__restrict__ sched_ctr) {
+    uint32_t *__restrict__ sched_ctr, const float *__restrict__ chk_g) {
     using L = Sweep4Lds;
     // NW wavefronts as 2 (samples) x WJ (prototypes), wavefront tile 64 x 32 JT: 4 -> 64 x 128,
     // 8 -> 64 x 64 (64 accumulator registers: <= 128 VGPRs, four wavefronts per SIMD)
@@ -1039,8 +1091,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
     int *prev_s = reinterpret_cast<int *>(smem + L::OFF_PREV);
     uint32_t *mask = reinterpret_cast<uint32_t *>(smem + L::OFF_MASK);
     int *misc = reinterpret_cast<int *>(smem + L::OFF_MISC);
-    const double *ytab = reinterpret_cast<const double *>(smem + L::OFF_TAB);
-    const double *ctb = ytab + BJ;
+    // chunk tables of the epilogue, float32 (see "float32 chunk epilogue" below): |w|^2 / c' and 1 / c'
+    // (MODE 0) or |w|^2 and c 2^16 (MODE 1) of the chunk's BJ prototypes
+    const float *ytab = reinterpret_cast<const float *>(smem + L::OFF_TAB);
+    const float *ctb = ytab + BJ;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1125,7 +1179,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
         if (need && q == 0) {
             const double T = sweep_T<PLANES>(a0, 0, 0);
             const double sv = sx[i], xv2 = xx[i];
-            const double e2 = 2.0 * filter_eps(sv, l1x[i], xv2, summary[0], summary[1], summary[2], d, PLANES);
+            const double e2 = 2.0 * filter_eps(sv, l1x[i], xv2, summary[0], summary[1], summary[2], d, PLANES) +
+                              epilogue32_slack(xv2, summary[2]);
             thr_s[il] = (sv * (craw[pj] * T) - yraw[pj]) - e2;
         }
         __syncthreads();
@@ -1141,10 +1196,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
 #pragma unroll
             for (int it = 0; it < 2; ++it)
                 eps_s[wi * 64 + it * 32 + lc] =
-                    2.0 * filter_eps(s_i[it], l1_i[it], xx_i[it], l1w_max, t_max, yy_max, d, PLANES);
+                    2.0 * filter_eps(s_i[it], l1_i[it], xx_i[it], l1w_max, t_max, yy_max, d, PLANES) +
+                    epilogue32_slack(xx_i[it], yy_max);
         }
     }
-    double bestv[2] = {INFINITY, INFINITY};  // MODE 1: running arg-min of r~
+    float bestv[2] = {INFINITY, INFINITY};  // MODE 1: running arg-min of r~ (float32: any seed will do)
     int bestj[2] = {0, 0};
 
     const int8_t *xsrc[XI];
@@ -1193,15 +1249,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
             }
         }
     };
-    // the chunk tables (4 pieces of 1 KiB: |w|^2 / c halves, 1 / c halves), one piece per wave 0 .. 3
-    const bool tab_wave = NW == 4 || wave < 4;
+    // the chunk tables (2 pieces of 1 KiB = 256 float32: |w|^2 / c', 1 / c'), one piece per wave 0, 1
+    const bool tab_wave = wave < 2;
     auto issue_tables = [&](int chunk) {
         if (!tab_wave) return;
-        const int half = wave & 1;
-        const int j2 = chunk * BJ + 128 * half + 2 * lane;  // tables are padded to whole 512-entry chunks
+        const int j4 = chunk * BJ + 4 * lane;  // tables are padded to whole 512-entry chunks
         char *tab = smem + L::OFF_TAB;
-        if (wave >= 2) fdma16(ctab_g + j2, tab + L::TAB + 1024 * half);
-        else fdma16(ytab_g + j2, tab + 1024 * half);
+        if (wave == 1) fdma16(ctab_g + j4, tab + 1024);
+        else fdma16(ytab_g + j4, tab);
     };
 
     int xoff[2], woff[JT];
@@ -1356,34 +1411,74 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
                 }
                 __syncthreads();
             }
-            double A_i[2] = {0.0, 0.0};
+            // float32 chunk epilogue.  The marking test r~_ij <= thr_i in the form
+            //     A_i (1 / c'_j) + |w_j|^2 / c'_j <= s_i T'_ij,    A_i = |x_i|^2 - thr_i,
+            // evaluated in float32 (an fma, a product, a conversion and a compare per pair -- the
+            // float64 form took twice the issue cycles, and at d <= 256 the epilogues, not the matrix
+            // products, are most of this kernel).  Marking MORE than the exact test would is always
+            // allowed, so the test is made one-sided: every float32 operand is within 2^-24 of its
+            // float64 value (table entries and A_i, s_i that are not normal float32 numbers are
+            // replaced by "always marked"), the fma, the product and the conversion of T' round
+            // once each, so the two sides are off by at most 3.1 2^-24 (|A_i / c'| + |w|^2 / c' +
+            // |s_i T'|) <= 3.1 2^-24 (|A_i| + |x_i|^2 + 2.1 max|w|^2) / c' -- thr_i carries that much
+            // extra slack (epilogue32_slack, and the 2.5e-7 |A_i| below), and a NaN marks.
+            float a32[2] = {0.f, 0.f}, s32[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) s32[it] = (float)s_i[it];
             if constexpr (MODE == 0) {
 #pragma unroll
-                for (int it = 0; it < 2; ++it) A_i[it] = thr_s[wi * 64 + it * 32 + lc];
+                for (int it = 0; it < 2; ++it) {
+                    const double A = thr_s[wi * 64 + it * 32 + lc];
+                    const double Am = A - 2.5e-7 * fabs(A);
+                    const bool inf = (A == INFINITY) || (A == -INFINITY);  // no sample / no bound yet
+                    const bool ok = f32_representable(Am) && f32_representable(s_i[it]) && s_i[it] != 0.0;
+                    a32[it] = inf ? (float)A : (ok ? (float)Am : -INFINITY);
+                }
+            }
+            // Coarse integer test in front of it: a lower bound Lmin_i <= fma(a_i, 1/c'_j, |w_j|^2/c'_j)
+            // over the WHOLE chunk (float32 fma and rounding are monotone: smallest table entries,
+            // the largest 1/c' for a negative a_i), turned into an integer T'_low with s_i T' < Lmin_i
+            // for every T' < T'_low (relative slack 4e-7 and one unit; NaN or -inf -> no bound).  A
+            // prototype row whose 64 accumulators all stay below their sample's T'_low cannot be
+            // marked by the test above and skips it: on clustered data that is nearly every row.
+            int tlow[2] = {(int)0x80000000, (int)0x80000000};
+            if constexpr (MODE == 0) {
+                const float4 ck = *reinterpret_cast<const float4 *>(chk_g + 4 * r_chunk);
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const float lmin = fmaf(a32[it], a32[it] >= 0.f ? ck.y : ck.z, ck.x);
+                    float q = lmin / s32[it];
+                    q = q - fabsf(q) * 4e-7f - 2.f;
+                    // (NaN, -inf, a non-positive or non-finite s: no bound -- INT_MIN)
+                    const bool bounded = (q == q) && q > -2.0e9f && s32[it] > 0.f;
+                    tlow[it] = bounded ? (q >= 2.0e9f ? 0x7fffffff : (int)floorf(q)) : (int)0x80000000;
+                }
             }
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
                 uint32_t word = 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    double y4[4], c4[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        y4[i] = ytab[jl0 + jt * 32 + 8 * g + i];
-                        c4[i] = ctb[jl0 + jt * 32 + 8 * g + i];
-                    }
+                    const float4 y4 = *reinterpret_cast<const float4 *>(ytab + jl0 + jt * 32 + 8 * g);
+                    const float4 c4 = *reinterpret_cast<const float4 *>(ctb + jl0 + jt * 32 + 8 * g);
+                    const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 4 * g + i;
                         uint64_t pass = 0;
+                        if constexpr (MODE == 0) {
+                            const uint64_t maybe = __builtin_amdgcn_ballot_w64(acc[jt][0][r] >= tlow[0]) |
+                                                   __builtin_amdgcn_ballot_w64(acc[jt][1][r] >= tlow[1]);
+                            if (maybe == 0) continue;   // wave-uniform: nobody can pass for this pair of rows
+                        }
 #pragma unroll
                         for (int it = 0; it < 2; ++it) {
+                            const float Tf = (float)acc[jt][it][r];
                             if constexpr (MODE == 0) {
-                                const double Tp = (double)acc[jt][it][r];
-                                pass |= __builtin_amdgcn_ballot_w64((A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp);
-                            } else {  // tables in plain form here: r~ - |x_i|^2 = |w|^2 - s c T
+                                pass |= __builtin_amdgcn_ballot_w64(!(fmaf(a32[it], cv[i], yv[i]) > s32[it] * Tf));
+                            } else {  // tables in plain form here: r~ - |x_i|^2 = |w|^2 - s (c 2^16) T'
                                 const int j = jc + jl0 + jt * 32 + 8 * g + i;
-                                const double rv = y4[i] - s_i[it] * (c4[i] * sweep_T<PLANES>(acc[jt][it][r], 0, 0));
+                                const float rv = yv[i] - s32[it] * (cv[i] * Tf);
                                 if (j < M && rv < bestv[it]) { bestv[it] = rv; bestj[it] = j * jstride; }
                             }
                         }
@@ -1423,11 +1518,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
     if constexpr (MODE == 1) {
         // seed = arg-min of r~ over the 2 lane halves and the 2 prototype wavefronts
         __syncthreads();
-        double *sv = reinterpret_cast<double *>(smem);           // [WJ][128]
+        float *sv = reinterpret_cast<float *>(smem);             // [WJ][128]
         int *sj = reinterpret_cast<int *>(smem + WJ * 128 * 8);  // [WJ][128]
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const double ov = __shfl_xor(bestv[it], 32, 64);
+            const float ov = __shfl_xor(bestv[it], 32, 64);
             const int oj = __shfl_xor(bestj[it], 32, 64);
             if (ov < bestv[it] || (ov == bestv[it] && oj < bestj[it])) { bestv[it] = ov; bestj[it] = oj; }
             if (lh == 0) {
@@ -1437,11 +1532,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
         }
         __syncthreads();
         if (tid < 128 && p0 + tid < N) {
-            double bv = sv[tid];
+            float bv = sv[tid];
             int bj = sj[tid];
 #pragma unroll
             for (int w = 1; w < WJ; ++w) {
-                const double ov = sv[w * 128 + tid];
+                const float ov = sv[w * 128 + tid];
                 const int oj = sj[w * 128 + tid];
                 if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
             }
@@ -1818,6 +1913,8 @@ struct FilterWs {
     int8_t *wt, *wt_sub;   // k-tile-major digit planes of the prototypes / of the pre-pass subset
     double *wscale, *wl1;  // M each
     double *ctab, *yypad, *ctab_sub, *yy_sub, *ictab, *yctab, *yy_part, *summary;
+    float *tab32;        // 4 x Mpad float32: [yctab | ictab | yy_sub | ctab_sub 2^16] for the 2-per-CU sweep's epilogue
+    float *chk32;        // Mpad / 256 x 4 float32: [min yctab, min ictab, max ictab, -] per 256-prototype chunk
     double *tile_score;  // dpad / 64
     double *tile_part;   // TS_RB x 2 x dpad
     int32_t *kt_sel;     // SW_MAX_KT
@@ -1841,6 +1938,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t o8 = take((size_t)Mpad * 8), o9 = take((size_t)Mpad * 8);
     const size_t o10 = take((size_t)Mpad * 8), o11 = take((size_t)Mpad * 8), o12 = take((size_t)Mpad * 8);
     const size_t o13 = take((size_t)(dpad / FKT) * 8), o14 = take((size_t)SW_MAX_KT * 4);
+    const size_t o18 = take((size_t)4 * Mpad * 4), o19 = take((size_t)(Mpad / 256) * 16);
     const size_t o15 = take((size_t)TS_RB * 2 * dpad * 8);
     const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
@@ -1856,6 +1954,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
         f->ictab = (double *)(base + o10); f->yctab = (double *)(base + o11);
         f->yy_part = (double *)(base + o12);
         f->tile_score = (double *)(base + o13); f->kt_sel = (int32_t *)(base + o14);
+        f->tab32 = (float *)(base + o18); f->chk32 = (float *)(base + o19);
         f->tile_part = (double *)(base + o15);
         f->summary = (double *)(base + o2); f->ulist = (uint16_t *)(base + o3);
         f->ucount = (uint32_t *)(base + o4); f->seed = (int64_t *)(base + o5);
@@ -2048,7 +2147,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     WTables tables;
     tables.ww = ww_dev; tables.ctab = f.ctab; tables.yypad = f.yypad; tables.ctab_sub = f.ctab_sub;
     tables.yy_sub = f.yy_sub; tables.ictab = f.ictab; tables.yctab = f.yctab; tables.summary = f.summary;
-    tables.sched_ctr = f.sched_ctr; tables.tscale = sweep_tscale(sweep_planes);
+    tables.sched_ctr = f.sched_ctr; tables.tscale = sweep_tscale(sweep_planes); tables.tab32 = f.tab32; tables.chk32 = f.chk32;
     hipLaunchKernelGGL(slice_w_tiled_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, W_dev,
                        (int)M, (int)d, dpad, (int)f.Mpad, seed_stride, Msubpad, nkt_used,
                        nkt_used < nkt_full ? f.kt_sel : (const int32_t *)nullptr, f.wt,
@@ -2065,9 +2164,10 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         }();
         if (sweep_planes == 1 && prepass_shape == 4)
             S4_LAUNCH(1, f.nb, xb.planes, xb.scale,
-                               xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub, f.yy_sub,
+                               xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.tab32 + 2 * (size_t)f.Mpad,
+                               f.tab32 + 3 * (size_t)f.Mpad, f.yy_sub,
                                f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
-                               f.ulist, (int)f.Mpad, f.ucount, Msubpad, f.seed, seed_stride, nkt_used, f.kt_sel, f.sched_ctr);
+                               f.ulist, (int)f.Mpad, f.ucount, Msubpad, f.seed, seed_stride, nkt_used, f.kt_sel, f.sched_ctr, f.chk32);
         else if (sweep_planes == 1)
             hipLaunchKernelGGL((sweep_i8_kernel<1, 1, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub,
@@ -2097,9 +2197,9 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     if (sweep_planes == 1 && sweep_shape == 4 && order_dev && M <= Sweep4Lds::MAX_M) {
         // one digit product, 4-wavefront workgroups (128 x 256 tile), two of them per CU
         S4_LAUNCH(0, f.nb, xb.planes, xb.scale,
-                           xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab, f.yypad, f.ctab,
+                           xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.tab32, f.tab32 + (size_t)f.Mpad, f.yypad, f.ctab,
                            f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int)f.Mpad, (int64_t *)nullptr, 1, 0, (const int32_t *)nullptr, f.sched_ctr);
+                           (int)f.Mpad, (int64_t *)nullptr, 1, 0, (const int32_t *)nullptr, f.sched_ctr, f.chk32);
     } else if (sweep_planes == 1) {  // one digit product: 128 x 512 tile (128 x 256 for small maps)
         if (M > 256) DBGSOM_SWEEP(1, 4); else DBGSOM_SWEEP(1, 2);
     } else if (sweep_planes == 3)
