@@ -210,8 +210,8 @@ class HipBackend(HotPathBackend):
     FILTER_MAX_MEAN_CANDIDATES = 320
     FILTER_MIN_QUERY_ROWS = 32768
     # cost model of the adaptive digit planes (mirrors engine.hip; tests recompute the choice)
-    SWEEP_COST = {1: 0.54, 2: 1.0, 3: 1.96}
-    LIST_COST = 16.4
+    SWEEP_COST = {1: 0.35, 2: 1.0, 3: 1.96}
+    LIST_COST = 12.5
 
     def __init__(self, device: Optional[int] = None, algorithm: str = "auto", _ctx=None):
         """algorithm (all give IDENTICAL results):
@@ -566,6 +566,12 @@ class HipBackend(HotPathBackend):
         out = np.empty(nb, dtype=np.uint32)
         self._call("dbgsom_ctx_filter_counts", self._ctx, out.ctypes.data, nb)
         return out
+
+    def traffic(self):
+        """PCIe traffic of the prototypes since the context was created / last released."""
+        keys = ("w_upload_calls", "w_upload_bytes", "w_download_calls", "w_download_bytes",
+                "w_row_writes", "w_row_reads")
+        return {k: self._get(k) for k in keys}
 
     def plane_cost(self, p, mean, M):
         return self.SWEEP_COST[p] * M + self.LIST_COST * mean

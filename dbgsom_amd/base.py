@@ -318,6 +318,7 @@ class BaseSom(BaseEstimator):
         resident = hasattr(engine, "write_weight_rows")
         on_device = False     # the current prototypes are in HBM, lat.W is stale
         ran = False
+        self._growth_epochs = []
         for epoch in epochs:
             self._current_epoch = epoch
             if epoch > self.coarse_training_frac * self.n_iter:
@@ -354,6 +355,7 @@ class BaseSom(BaseEstimator):
                     lat.set_weights(engine.get_weights(0))   # growth extrapolates from W'
                     m_before = len(lat)
                     lat.grow(self.growing_threshold_, epoch)
+                    self._growth_epochs.append(epoch)
                     for i in lat.pop_overwritten():           # occupied positions (rare)
                         engine.write_weight_rows(i, lat.W[i])
                     if len(lat) > m_before:                   # the inserted rows only
@@ -363,6 +365,8 @@ class BaseSom(BaseEstimator):
         if on_device and ran:
             self.weights_ = engine.get_weights(1)   # the snapshot the last epoch consumed (Q3)
             lat.set_weights(engine.get_weights(0))
+        if hasattr(engine, "traffic"):
+            self._training_traffic = engine.traffic()   # what crossed PCIe during the epoch loop
         lat.write_attributes()
 
     def _gamma(self) -> float:

@@ -160,9 +160,11 @@ constexpr int64_t FILTER_MIN_PROTOTYPES = 129;  // at or below 128 one chunk of 
 constexpr int64_t FILTER_MAX_FEATURES = 43690;  // int32 digit-product accumulators: 3 x 128 x 128 x d < 2^31
 constexpr int FILTER_BACKOFF = 8;
 constexpr int PLANES_REPROBE = 64;
-// cost model of the candidate sweep (per prototype) against a list entry of the exact stage
-const double SWEEP_COST[4] = {0.0, 0.54, 1.0, 1.96};
-constexpr double LIST_COST = 16.4;
+// cost model of the candidate sweep (per prototype, in units of the three-product sweep) against a
+// list entry of the exact stage -- measured at C4 with this build's kernels: one product 1.00 ms,
+// three 2.87 ms per 1024 prototypes; exact stage 1.16 ms per 33 list entries
+const double SWEEP_COST[4] = {0.0, 0.35, 1.0, 1.96};
+constexpr double LIST_COST = 12.5;
 
 struct Samples {  // one resident sample set (training samples, or a query batch)
     int dtype = -1;            // storage dtype in HBM
@@ -227,6 +229,9 @@ struct dbgsom_ctx {
     // collective
     dbgsom_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
+    // traffic of the prototypes across PCIe (f-4 evidence: whole matrices only at the first epoch, at
+    // growth steps and at the end of a fit)
+    int64_t w_up_calls = 0, w_up_bytes = 0, w_down_calls = 0, w_down_bytes = 0, w_row_writes = 0, w_row_reads = 0;
     // timing
     hipEvent_t ev[4] = {};
     bool ev_created = false, ev_valid = false;
@@ -352,6 +357,7 @@ int stage_weights(dbgsom_ctx *c, const double *W_host, int64_t M, int64_t d, int
         TRY(c->Wb[c->cur].reserve((size_t)M * dp * 8));
         TRY(upload_padded(c, c->Wb[c->cur].p, W_host, M, d, dp, 8));
         c->M = M;
+        ++c->w_up_calls; c->w_up_bytes += M * d * 8;
     } else if (c->M != M) {
         set_error("no resident prototypes of %lld rows (resident: %lld); pass W_host or call dbgsom_ctx_set_weights",
                   (long long)M, (long long)c->M);
@@ -525,7 +531,10 @@ int smooth_and_fetch(dbgsom_ctx *c, int64_t M, double sigma, int layout, int fla
         TRY(c->counts.reserve((size_t)nb * 4));
         TRY(dbgsom_bmu_filtered_counts_async(c->filt_ws.p, s.N, dp, M, c->counts.as<uint32_t>(), nb, c->stream));
     }
-    if (W_new_host) TRY(download_unpadded(c, W_new_host, c->Wb[nxt].p, M, d, dp, 8));
+    if (W_new_host) {
+        TRY(download_unpadded(c, W_new_host, c->Wb[nxt].p, M, d, dp, 8));
+        ++c->w_down_calls; c->w_down_bytes += M * d * 8;
+    }
     if (idx_host) DBGSOM_HIP_CHECK(hipMemcpyAsync(idx_host, idx_dev, (size_t)s.N * 8, hipMemcpyDeviceToHost, c->stream));
     if (dist_host) DBGSOM_HIP_CHECK(hipMemcpyAsync(dist_host, c->dist.p, (size_t)s.N * 8, hipMemcpyDeviceToHost, c->stream));
     TRY(sync(c));
@@ -668,6 +677,12 @@ int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
     else if (!strcmp(name, "hint_valid")) *v = c->hint_valid ? 1 : 0;
     else if (!strcmp(name, "filter_backoff")) *v = c->filter_backoff;
     else if (!strcmp(name, "plane_hold")) *v = c->plane_hold;
+    else if (!strcmp(name, "w_upload_calls")) *v = c->w_up_calls;
+    else if (!strcmp(name, "w_upload_bytes")) *v = c->w_up_bytes;
+    else if (!strcmp(name, "w_download_calls")) *v = c->w_down_calls;
+    else if (!strcmp(name, "w_download_bytes")) *v = c->w_down_bytes;
+    else if (!strcmp(name, "w_row_writes")) *v = c->w_row_writes;
+    else if (!strcmp(name, "w_row_reads")) *v = c->w_row_reads;
     else if (!strcmp(name, "device_bytes")) {
         size_t tot = c->xs.own.cap + c->xs.x32.cap + c->xs.xx.cap + c->xs.planes.cap + c->xq.own.cap + c->xq.x32.cap +
                      c->xq.xx.cap + c->xq.planes.cap;
@@ -805,6 +820,7 @@ int dbgsom_ctx_set_weights(dbgsom_ctx *c, const double *W_host, int64_t M) {
     TRY(c->Wb[c->cur].reserve((size_t)M * c->xs.dp * 8));
     TRY(upload_padded(c, c->Wb[c->cur].p, W_host, M, c->xs.d, c->xs.dp, 8));
     c->M = M;
+    ++c->w_up_calls; c->w_up_bytes += M * c->xs.d * 8;
     return sync(c);
 }
 
@@ -819,6 +835,7 @@ int dbgsom_ctx_get_weights(dbgsom_ctx *c, int which, double *W_host, int64_t M) 
         return DBGSOM_ESTATE;
     }
     TRY(download_unpadded(c, W_host, c->Wb[b].p, M, c->xs.d, c->xs.dp, 8));
+    ++c->w_down_calls; c->w_down_bytes += M * c->xs.d * 8;
     return sync(c);
 }
 
@@ -829,6 +846,7 @@ int dbgsom_ctx_read_weight_rows(dbgsom_ctx *c, int which, const int64_t *rows_ho
     const int b = which ? c->cur ^ 1 : c->cur;
     const int64_t have = which ? c->otherM : c->M;
     const int64_t d = c->xs.d, dp = c->xs.dp;
+    c->w_row_reads += n;
     for (int64_t r = 0; r < n; ++r) {
         DBGSOM_REQUIRE(rows_host[r] >= 0 && rows_host[r] < have, "row index out of range");
         DBGSOM_HIP_CHECK(hipMemcpyAsync(out_host + r * d, c->Wb[b].as<double>() + rows_host[r] * dp, (size_t)d * 8,
@@ -848,6 +866,7 @@ int dbgsom_ctx_write_weight_rows(dbgsom_ctx *c, int64_t row0, int64_t n, const d
     double *dst = c->Wb[c->cur].as<double>() + row0 * dp;
     TRY(upload_padded(c, dst, rows_host, n, d, dp, 8));
     c->M = newM;
+    c->w_row_writes += n;
     return sync(c);
 }
 

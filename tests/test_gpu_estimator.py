@@ -68,6 +68,24 @@ def test_predict_accepts_integer_and_half_input_like_the_reference():
     assert np.array_equal(clf.predict(Xd.astype(np.int32)), clf.predict(Xd))
 
 
+def test_prototypes_stay_in_hbm_between_epochs():
+    """during the epoch loop the prototype matrix crosses PCIe once on the way in
+    (the four start vectors), comes back only at growth steps (the host extrapolates the inserted
+    rows from it) and at the end; a growth step uploads the inserted rows only."""
+    from dbgsom_amd import SomVQ
+
+    X, _ = gi.case_X("blobs_dead")
+    est = SomVQ(**gi.EST_KWARGS["blobs_dead"]).fit(X)
+    g = gi.load("blobs_dead")
+    np.testing.assert_allclose(est.weights_, g["final_weights"], rtol=1e-8, atol=1e-10)
+    tr, growth = est._training_traffic, est._growth_epochs
+    assert est.n_iter_ + 1 >= 30 and len(growth) >= 3
+    assert tr["w_upload_calls"] == 1 and tr["w_upload_bytes"] == 4 * X.shape[1] * 8   # epoch 0: the 2 x 2 start map
+    assert tr["w_download_calls"] == len(growth) + 2                  # growth steps + the two final snapshots
+    assert tr["w_row_writes"] >= len(growth)                          # inserted (and overwritten) rows only
+    assert tr["w_row_writes"] < 4 * len(est.neurons_)
+
+
 def test_full_size_c5_shard_properties():
     """One GPU's shard of BASELINE config C5 at its real shape (N = 5e5, d = 2048, M = 4096,
     bfloat16-resident samples): the filtered search equals the all-pairs search on the full

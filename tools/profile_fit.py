@@ -28,4 +28,10 @@ pr.disable()
 t = time.perf_counter() - t0
 print(f"fit: {t:.2f} s, epochs {est.n_iter_ + 1}, neurons {len(est.neurons_)}, "
       f"QE {est.quantization_error_:.4f} TE {est.topographic_error_:.4f}")
+tr = est._training_traffic
+M = len(est.neurons_)
+print(f"prototype traffic over PCIe during the epoch loop ({est.n_iter_ + 1} epochs, {len(est._growth_epochs)} growth "
+      f"steps, final M = {M}, M x d x 8 = {M * d * 8 / 1e6:.2f} MB): whole-matrix uploads {tr['w_upload_calls']} "
+      f"({tr['w_upload_bytes'] / 1e6:.2f} MB), whole-matrix downloads {tr['w_download_calls']} "
+      f"({tr['w_download_bytes'] / 1e6:.2f} MB), single rows written {tr['w_row_writes']}, read {tr['w_row_reads']}")
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
