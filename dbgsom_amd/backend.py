@@ -309,18 +309,27 @@ class HipBackend(HotPathBackend):
 
         dev = torch.device("cuda", self.device_index)
         on_device = td.get_backend() == "nccl"
+        cache = {}   # the context reuses its stream and (until the map grows) its sums buffer
 
         def reduce(_user, ptr, count, stream):
             try:
-                with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
-                    t = torch.as_tensor(_DeviceArray(ptr, count), device=dev)
+                ext = cache.get(("stream", stream))
+                if ext is None:
+                    ext = cache[("stream", stream)] = torch.cuda.ExternalStream(stream, device=dev)
+                with torch.cuda.stream(ext):
+                    t = cache.get((ptr, count))
+                    if t is None:
+                        if len(cache) > 16:
+                            cache.clear()
+                            cache[("stream", stream)] = ext
+                        t = cache[(ptr, count)] = torch.as_tensor(_DeviceArray(ptr, count), device=dev)
                     if on_device:
                         td.all_reduce(t, op=td.ReduceOp.SUM)   # RCCL, ordered on the context's stream
                     else:  # gloo and friends: through the host (tests: several ranks on one GPU)
                         h = t.cpu()
                         td.all_reduce(h, op=td.ReduceOp.SUM)
                         t.copy_(h)
-                        torch.cuda.current_stream().synchronize()
+                        ext.synchronize()
                 return 0
             except BaseException as e:  # nothing may propagate through the C frames
                 self._cb_error = e

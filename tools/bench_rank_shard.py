@@ -16,12 +16,12 @@ from dbgsom_amd.backend import HipBackend  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c4"
 ranks = [int(r) for r in sys.argv[2:]] or [0, 1]
-n, d, rows, cols, seed, _ = bench.WORKLOADS[name]
+n, d, rows, cols, seed, kind, _ = bench.WORKLOADS[name]
 M = rows * cols
 dev = torch.device("cuda", 0)
 X0 = bench.make_shard(torch, n, d, seed, dev)
 g = torch.Generator(device=dev).manual_seed(seed + 7)
-W = X0[torch.randperm(n, device=dev, generator=g)[:M]].double().contiguous()
+W = X0[torch.randperm(n, device=dev, generator=g)[:M]].double().cpu().numpy()
 gamma = float(1.0 / X0.double().var(dim=0, unbiased=False).sum().item())
 del X0
 hop = bench.lattice_hops(rows, cols)
