@@ -219,6 +219,11 @@ struct dbgsom_ctx {
     int64_t planeM = -1;
     double plane_known[4] = {NAN, NAN, NAN, NAN};
     int plane_hold = 0;
+    // stateless seeds: 0 = the cheap pre-pass (a subset of prototypes and features), 1 = the full one
+    int seed_mode = 0, seed_hold = 0;
+    double seed_known[2] = {NAN, NAN};
+    int64_t seedM = -1;
+    bool last_seed_full = false;
     // last epoch
     bool last_filtered = false, last_hinted = false;
     double last_mean = NAN;
@@ -373,8 +378,10 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     TRY(ensure_planes(c, s));
     TRY(ws.reserve_zeroed(dbgsom_bmu_filtered_workspace_bytes(s.N, s.dp, M), c->stream));
     c->planes_used = planes_for_call(c);
+    c->last_seed_full = !prev_idx && c->seed_mode == 1 && c->seed_stride == 0;
+    const int stride = c->last_seed_full ? DBGSOM_SEED_FULL : c->seed_stride;
     TRY(dbgsom_bmu_filtered(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), s.planes.p, W, M,
-                            c->ww.as<double>(), prev_idx, order, c->seed_stride, c->planes_used, round_f32, idx,
+                            c->ww.as<double>(), prev_idx, order, stride, c->planes_used, round_f32, idx,
                             dist, ws.p, ws.cap, c->stream));
     c->last_filter_M = M; c->last_filter_N = s.N; c->last_filter_d = s.dp; c->last_filter_ws = ws.p;
     return DBGSOM_OK;
@@ -423,6 +430,33 @@ void adapt_planes(dbgsom_ctx *c, double mean, int64_t M) {
     }
 }
 
+// Stateless searches (no previous winners): the cheap seed pre-pass (every 4th .. 64th prototype on
+// three 64-feature blocks) or the full one (every prototype, every feature: one more sweep).  On
+// clustered data any seed of the right cluster will do; on weakly clustered data a seed that is not
+// nearly the winner leaves most of the map a candidate.  Same two-armed scheme as the digit planes:
+// try the full pre-pass when the lists are long enough for it to pay even if it emptied them, keep
+// the cheaper arm in the cost model, look again every PLANES_REPROBE epochs.
+void adapt_seeds(dbgsom_ctx *c, double mean, int64_t M) {
+    if (c->seedM != M) { c->seedM = M; c->seed_known[0] = c->seed_known[1] = NAN; c->seed_hold = 0; }
+    const int mode = c->last_seed_full ? 1 : 0;
+    c->seed_known[mode] = mean;
+    if (c->seed_hold > 0) {
+        if (--c->seed_hold == 0) c->seed_known[1 - mode] = NAN;
+        return;
+    }
+    const double sweep = SWEEP_COST[c->planes_used] * (double)M;
+    auto cost = [&](int m) { return (m ? 2.0 : 1.15) * sweep + LIST_COST * c->seed_known[m]; };
+    if (isnan(c->seed_known[1])) {
+        c->seed_mode = (LIST_COST * c->seed_known[0] > 0.85 * sweep) ? 1 : 0;   // worth a look?
+        if (c->seed_mode == 0) c->seed_hold = PLANES_REPROBE;
+    } else if (isnan(c->seed_known[0])) {
+        c->seed_mode = 0;
+    } else {
+        c->seed_mode = cost(1) < cost(0) ? 1 : 0;
+        c->seed_hold = PLANES_REPROBE;
+    }
+}
+
 // after an epoch has completed: look at how long the candidate lists were, decide what comes next
 void update_policy(dbgsom_ctx *c, const uint32_t *counts, int64_t nb, int64_t M) {
     if (!c->last_filtered) { c->last_mean = NAN; return; }
@@ -430,6 +464,7 @@ void update_policy(dbgsom_ctx *c, const uint32_t *counts, int64_t nb, int64_t M)
     for (int64_t b = 0; b < nb; ++b) sum += counts[b];
     const double mean = nb ? sum / (double)nb : 0.0;
     c->last_mean = mean;
+    if (!c->last_hinted && c->seed_stride == 0) adapt_seeds(c, mean, M);
     if (c->sweep_planes == 0) adapt_planes(c, mean, M);
     if (c->algorithm == DBGSOM_ALG_AUTO) {
         if (mean > (double)c->max_mean_candidates) {  // exponential back-off, capped
@@ -677,6 +712,7 @@ int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
     else if (!strcmp(name, "hint_valid")) *v = c->hint_valid ? 1 : 0;
     else if (!strcmp(name, "filter_backoff")) *v = c->filter_backoff;
     else if (!strcmp(name, "plane_hold")) *v = c->plane_hold;
+    else if (!strcmp(name, "seed_mode")) *v = c->seed_mode;
     else if (!strcmp(name, "w_upload_calls")) *v = c->w_up_calls;
     else if (!strcmp(name, "w_upload_bytes")) *v = c->w_up_bytes;
     else if (!strcmp(name, "w_download_calls")) *v = c->w_down_calls;
@@ -715,6 +751,7 @@ static void reset_training_state(dbgsom_ctx *c) {
     c->planes_next = 1;
     c->planeM = -1;
     c->plane_hold = 0;
+    c->seed_mode = 0; c->seed_hold = 0; c->seedM = -1;
     c->last_filtered = false;
     c->last_mean = NAN;
     c->sumsM = 0;
@@ -1255,7 +1292,7 @@ int dbgsom_ctx_epoch_info(dbgsom_ctx *c, double *info8) {
     info8[4] = (double)c->filter_backoff;
     info8[5] = (double)c->plane_hold;
     info8[6] = 0.0;
-    info8[7] = 0.0;
+    info8[7] = c->last_filtered && c->last_seed_full ? 1.0 : 0.0;
     return DBGSOM_OK;
 }
 

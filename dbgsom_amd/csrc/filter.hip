@@ -2096,6 +2096,10 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         else                                                                                       \
             hipLaunchKernelGGL((sweep4_i8_kernel<MODE_, 4>), dim3((unsigned)(NB)), dim3(256), 0, s, __VA_ARGS__); \
     } while (0)
+    // DBGSOM_SEED_FULL: the seed pre-pass looks at EVERY prototype and every feature (as expensive
+    // as the sweep it seeds; what weakly clustered data needs -- the engine's policy decides)
+    const bool seed_full = (seed_stride & DBGSOM_SEED_FULL) != 0;
+    seed_stride = seed_full ? 1 : seed_stride;
     DBGSOM_REQUIRE(seed_stride >= 0 && seed_stride <= 64, "seed_stride outside [0, 64]");
     DBGSOM_REQUIRE(sweep_planes >= 0 && sweep_planes <= 3, "sweep_planes must be 0 .. 3");
     if (sweep_planes == 0) sweep_planes = 2;
@@ -2137,7 +2141,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         return e ? atoi(e) : PREPASS_KTILES;
     }();
     const int nkt_full = dpad / FKT;
-    const int nkt_used = (prepass_env >= 2 && prepass_env < nkt_full && nkt_full <= SW_MAX_KT) ? prepass_env : nkt_full;
+    const int nkt_used = (!seed_full && prepass_env >= 2 && prepass_env < nkt_full && nkt_full <= SW_MAX_KT) ? prepass_env : nkt_full;
     if (nkt_used < nkt_full) {
         hipLaunchKernelGGL(tile_partial_kernel, dim3((unsigned)nkt_full, TS_RB), dim3(256), 0, s, W_dev,
                            (int)M, (int)d, dpad, f.tile_part);

@@ -48,6 +48,11 @@ extern "C" {
 #define DBGSOM_ERANGE (-5)   /* a winner index outside [0, M) was met */
 #define DBGSOM_ECALLBACK (-6) /* the caller's all-reduce callback reported a failure */
 
+/* OR-ed into `seed_stride` of dbgsom_bmu_filtered: the stateless seed pre-pass looks at every
+ * prototype and every feature (as expensive as the candidate sweep it seeds; pays on weakly
+ * clustered data, where cheap seeds leave nearly every prototype a candidate) */
+#define DBGSOM_SEED_FULL 0x100
+
 /* prototype-count limit of the accumulate step (per-block LDS histogram) */
 #define DBGSOM_MAX_PROTOTYPES 16000
 
@@ -347,7 +352,7 @@ int dbgsom_ctx_subset_create(dbgsom_ctx *ctx, int64_t neuron, dbgsom_ctx **child
 /* ---- diagnostics ----------------------------------------------------------------------------- */
 /* info8 = [filtered search ran (0/1), mean candidate-list length, digit planes used, seeds were
  *          previous winners (0/1), back-off epochs left, plane-policy hold, launches replayed from
- *          a graph (0/1), reserved] of the last epoch */
+ *          a graph (0/1), stateless seeds came from the full pre-pass (0/1)] of the last epoch */
 int dbgsom_ctx_epoch_info(dbgsom_ctx *ctx, double *info8);
 /* candidate-list length per 128-sample workgroup of the last filtered search (n = ceil(N/128)) */
 int dbgsom_ctx_filter_counts(dbgsom_ctx *ctx, uint32_t *counts_host, int64_t n);

@@ -766,6 +766,36 @@ def test_filtered_search_randomised_shapes_dtypes_and_options():
         fi.release()
 
 
+def test_full_seed_prepass_on_weakly_clustered_data(o):
+    """Isotropic data: the cheap stateless seeds (a subset of prototypes and features) leave nearly
+    every prototype a candidate; the engine's seed policy moves to the full pre-pass (every
+    prototype, every feature) and the lists collapse.  Results are those of the all-pairs kernel
+    either way."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(21)
+    N, d, rows, cols = 30_000, 256, 20, 20
+    M = rows * cols
+    X = rng.normal(size=(N, d)).astype(np.float32)
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    hop = gi.lattice_hops(rows, cols)
+    fi = HipBackend(algorithm="filtered").load(X)
+    ex = HipBackend(algorithm="exact").load(X)
+    means, modes = [], []
+    for e in range(5):
+        rf = fi.epoch(W, hop, 3.0, 1e-3, "compact", True)
+        re_ = ex.epoch(W, hop, 3.0, 1e-3, "compact", True)
+        assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances)
+        assert np.array_equal(rf.new_weights, re_.new_weights, equal_nan=True)
+        means.append(fi.filter_log[-1][1])
+        modes.append(fi._get("seed_mode"))
+    assert means[0] > 0.5 * M                       # cheap seeds: (nearly) everything is a candidate
+    assert modes[-1] == 1 and means[-1] < 0.25 * M, (means, modes)
+    pick = rng.choice(N, 1000, replace=False)
+    rd, ri = o.bmu_chain(X[pick], W, 1)
+    assert np.array_equal(rf.winners[pick], ri) and np.array_equal(rf.distances[pick], rd)
+
+
 def test_adaptive_digit_planes_settle_on_the_cheaper_sweep(o):
     """sweep_planes = 0: starts with the one-product sweep; keeps it where the lists stay short
     (clustered data), moves to three products where the coarse bound marks the whole map."""
