@@ -766,6 +766,38 @@ def test_filtered_search_randomised_shapes_dtypes_and_options():
         fi.release()
 
 
+@pytest.mark.parametrize("lo,hi", [(-12, 12), (-30, 5), (-5, 18)])
+def test_filtered_search_with_extreme_row_scales(lo, hi):
+    """Rows whose magnitudes span dozens of decades: the float32 chunk epilogue of the candidate
+    sweep replaces operands that are not normal float32 numbers by "always marked" and otherwise
+    keeps a rigorous slack; winners, distances and new prototypes stay those of the all-pairs
+    kernel, bit for bit (zero rows and denormal-range rows included)."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(1000 + hi - lo)
+    N, d, M = 6000, 96, 400
+    X = (rng.normal(size=(N, d)) * 10.0 ** rng.uniform(lo, hi, size=(N, 1))).astype(np.float32)
+    X[::97] = 0.0
+    W = rng.normal(size=(M, d)) * 10.0 ** rng.uniform(lo, hi, size=(M, 1))
+    W[5] = 0.0
+    W[6] = X[3].astype(np.float64)
+    hop = np.abs(np.subtract.outer(np.arange(M), np.arange(M))).astype(np.float64)
+    ex = HipBackend(algorithm="exact").load(X)
+    for planes in (1, 2, 0):
+        fi = HipBackend(algorithm="filtered").load(X)
+        fi.sweep_planes = planes
+        for e in range(2):
+            re_ = ex.epoch(W, hop, 1.5, 1e-30, "aligned", True)
+            rf = fi.epoch(W, hop, 1.5, 1e-30, "aligned", True)
+            assert fi.filter_log[-1][0] == "filtered"
+            assert np.array_equal(re_.winners, rf.winners), (planes, e)
+            assert np.array_equal(re_.distances, rf.distances), (planes, e)
+            assert np.array_equal(re_.new_weights, rf.new_weights, equal_nan=True), (planes, e)
+            fi.algorithm = "filtered_hint"
+        fi.release()
+    ex.release()
+
+
 def test_full_seed_prepass_on_weakly_clustered_data(o):
     """Isotropic data: the cheap stateless seeds (a subset of prototypes and features) leave nearly
     every prototype a candidate; the engine's seed policy moves to the full pre-pass (every
