@@ -217,12 +217,10 @@ struct dbgsom_ctx {
     int filter_backoff = 0, filter_fail = 0;
     int planes_next = 1, planes_used = 1;
     int64_t planeM = -1;
-    double plane_known[4] = {NAN, NAN, NAN, NAN};
+    double arm_known[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};  // [seeds][planes]
     int plane_hold = 0;
-    // stateless seeds: 0 = the cheap pre-pass (a subset of prototypes and features), 1 = the full one
-    int seed_mode = 0, seed_hold = 0;
-    double seed_known[2] = {NAN, NAN};
-    int64_t seedM = -1;
+    int seed_mode = 0;   // stateless seeds: 0 = the cheap pre-pass, 1 = the full one
+    double best_mean = NAN;  // list length of the cheapest known arm (what the back-off looks at)
     bool last_seed_full = false;
     // last epoch
     bool last_filtered = false, last_hinted = false;
@@ -398,62 +396,76 @@ int run_allreduce(dbgsom_ctx *c, double *buf, int64_t count) {
     return DBGSOM_OK;
 }
 
-void adapt_planes(dbgsom_ctx *c, double mean, int64_t M) {
+// What the next filtered search runs: an ARM = (seeds, digit planes).  Seeds: 0 = the cheap stateless
+// pre-pass (every 4th .. 64th prototype on three 64-feature blocks), 1 = the full one (every
+// prototype, every feature: one more sweep), 2 = the previous epoch's winners (not a choice: whenever
+// the caller's algorithm allows them and they exist).  Digit planes 1 .. 3 of the candidate sweep.
+// Cost model per arm: seeds {1.15, 2, 1} x SWEEP_COST[planes] x M + LIST_COST x mean list length.
+// The lists of an arm are only known once it has run, so the policy explores: from the cheapest
+// known arm it tries an unknown arm when even EMPTY lists would make it cheaper -- its neighbours
+// (one coordinate changed) first, and, when the lists are long (weakly clustered data: a seed that
+// is not nearly the winner, or a bound as wide as the spread of the distances, leaves most of the
+// map a candidate), the strong corner (full seeds, three products) directly: on isotropic data no
+// single step leads there (full seeds alone: 1024 candidates, finer planes alone: 981, both: 17).
+// When nothing is left to try it stays for PLANES_REPROBE epochs, then forgets the alternatives.
+// Results never depend on any of this.
+void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
+    const int row = c->last_hinted ? 2 : (c->last_seed_full ? 1 : 0);
     const int p = c->planes_used;
     if (c->planeM != M) {  // another map size: what was learnt no longer applies
         c->planeM = M;
-        for (double &k : c->plane_known) k = NAN;
+        for (auto &r : c->arm_known) for (double &k : r) k = NAN;
         c->plane_hold = 0;
     }
-    c->plane_known[p] = mean;
+    c->arm_known[row][p] = mean;
     if (c->plane_hold > 0) {
+        c->best_mean = mean;
         if (--c->plane_hold == 0) {  // forget the alternatives, they get another look
-            for (double &k : c->plane_known) k = NAN;
-            c->plane_known[p] = mean;
+            for (auto &r : c->arm_known) for (double &k : r) k = NAN;
+            c->arm_known[row][p] = mean;
         }
         return;
     }
-    auto cost = [&](int q) { return SWEEP_COST[q] * (double)M + LIST_COST * c->plane_known[q]; };
-    int best = 0;
-    for (int q = 1; q <= 3; ++q)
-        if (!isnan(c->plane_known[q]) && (best == 0 || cost(q) < cost(best))) best = q;
-    // a finer sweep can at best empty the lists; a coarser one is simply tried
-    const int finer = best + 1, coarser = best - 1;
-    if (finer <= 3 && isnan(c->plane_known[finer]) &&
-        LIST_COST * c->plane_known[best] > (SWEEP_COST[finer] - SWEEP_COST[best]) * (double)M)
-        c->planes_next = finer;
-    else if (coarser >= 1 && isnan(c->plane_known[coarser]))
-        c->planes_next = coarser;
-    else {
-        c->planes_next = best;
-        c->plane_hold = PLANES_REPROBE;
+    static const double SEED_COST[3] = {1.15, 2.0, 1.0};
+    auto fixed = [&](int s_, int q) { return SEED_COST[s_] * SWEEP_COST[q] * (double)M; };
+    auto allowed = [&](int s_, int q) {
+        if (c->sweep_planes && q != c->sweep_planes) return false;        // planes fixed by the caller
+        if (row == 2) return s_ == 2;                                      // hinted: only the planes vary
+        return s_ == 0 || (s_ == 1 && c->seed_stride == 0);               // a caller's stride: cheap seeds only
+    };
+    int bs = row, bp = p;
+    double bc = fixed(row, p) + LIST_COST * mean;
+    for (int s_ = 0; s_ < 3; ++s_)
+        for (int q = 1; q <= 3; ++q)
+            if (allowed(s_, q) && !isnan(c->arm_known[s_][q])) {
+                const double cst = fixed(s_, q) + LIST_COST * c->arm_known[s_][q];
+                if (cst < bc) { bc = cst; bs = s_; bp = q; }
+            }
+    // unknown arms worth a look, cheapest optimistic cost first
+    int es = -1, ep = -1;
+    double ec = bc;
+    auto consider = [&](int s_, int q) {
+        if (s_ < 0 || s_ > 2 || q < 1 || q > 3 || !allowed(s_, q) || !isnan(c->arm_known[s_][q])) return;
+        const double opt = fixed(s_, q);
+        if (opt < ec) { ec = opt; es = s_; ep = q; }
+    };
+    const double best_mean = (bs == row && bp == p) ? mean : c->arm_known[bs][bp];
+    c->best_mean = best_mean;
+    if (best_mean > fmax(96.0, (double)M / 8.0)) {   // long lists: the strong corner first
+        consider(bs == 2 ? 2 : 1, 2);
+        if (es < 0) consider(bs == 2 ? 2 : 1, 3);
     }
-}
-
-// Stateless searches (no previous winners): the cheap seed pre-pass (every 4th .. 64th prototype on
-// three 64-feature blocks) or the full one (every prototype, every feature: one more sweep).  On
-// clustered data any seed of the right cluster will do; on weakly clustered data a seed that is not
-// nearly the winner leaves most of the map a candidate.  Same two-armed scheme as the digit planes:
-// try the full pre-pass when the lists are long enough for it to pay even if it emptied them, keep
-// the cheaper arm in the cost model, look again every PLANES_REPROBE epochs.
-void adapt_seeds(dbgsom_ctx *c, double mean, int64_t M) {
-    if (c->seedM != M) { c->seedM = M; c->seed_known[0] = c->seed_known[1] = NAN; c->seed_hold = 0; }
-    const int mode = c->last_seed_full ? 1 : 0;
-    c->seed_known[mode] = mean;
-    if (c->seed_hold > 0) {
-        if (--c->seed_hold == 0) c->seed_known[1 - mode] = NAN;
-        return;
+    if (es < 0) {
+        consider(bs, bp + 1); consider(bs, bp - 1);
+        if (bs != 2) consider(1 - bs, bp);
     }
-    const double sweep = SWEEP_COST[c->planes_used] * (double)M;
-    auto cost = [&](int m) { return (m ? 2.0 : 1.15) * sweep + LIST_COST * c->seed_known[m]; };
-    if (isnan(c->seed_known[1])) {
-        c->seed_mode = (LIST_COST * c->seed_known[0] > 0.85 * sweep) ? 1 : 0;   // worth a look?
-        if (c->seed_mode == 0) c->seed_hold = PLANES_REPROBE;
-    } else if (isnan(c->seed_known[0])) {
-        c->seed_mode = 0;
+    if (es >= 0) {
+        c->seed_mode = es == 1 ? 1 : 0;
+        c->planes_next = ep;
     } else {
-        c->seed_mode = cost(1) < cost(0) ? 1 : 0;
-        c->seed_hold = PLANES_REPROBE;
+        c->seed_mode = bs == 1 ? 1 : 0;
+        c->planes_next = bp;
+        c->plane_hold = PLANES_REPROBE;
     }
 }
 
@@ -464,10 +476,10 @@ void update_policy(dbgsom_ctx *c, const uint32_t *counts, int64_t nb, int64_t M)
     for (int64_t b = 0; b < nb; ++b) sum += counts[b];
     const double mean = nb ? sum / (double)nb : 0.0;
     c->last_mean = mean;
-    if (!c->last_hinted && c->seed_stride == 0) adapt_seeds(c, mean, M);
-    if (c->sweep_planes == 0) adapt_planes(c, mean, M);
+    adapt_arms(c, mean, M);
     if (c->algorithm == DBGSOM_ALG_AUTO) {
-        if (mean > (double)c->max_mean_candidates) {  // exponential back-off, capped
+        // (the cheapest arm known so far, not an arm that is only being looked at)
+        if (c->best_mean > (double)c->max_mean_candidates) {  // exponential back-off, capped
             c->filter_fail = c->filter_fail < 6 ? c->filter_fail + 1 : 6;
             c->filter_backoff = FILTER_BACKOFF << (c->filter_fail - 1);
         } else {
@@ -751,7 +763,7 @@ static void reset_training_state(dbgsom_ctx *c) {
     c->planes_next = 1;
     c->planeM = -1;
     c->plane_hold = 0;
-    c->seed_mode = 0; c->seed_hold = 0; c->seedM = -1;
+    c->seed_mode = 0;
     c->last_filtered = false;
     c->last_mean = NAN;
     c->sumsM = 0;

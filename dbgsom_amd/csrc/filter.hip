@@ -1621,7 +1621,7 @@ __global__ __launch_bounds__(256) void sched_fill_kernel(const uint32_t *__restr
 // takes the workgroups whose list length falls in its class (<= 16, 17..32, > 32) so that the
 // gathered X tile is streamed once for all but the longest lists (a fourth class of 64 was
 // measured: no gain at C3 / C4, slower at C2).
-template <typename XT, int JTL, int NWV>
+template <typename XT, int JTL, int NWV, int SPLIT = 1>
 __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
     const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
     const double *__restrict__ W, int M, const double *__restrict__ ww,
@@ -1632,11 +1632,14 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
     constexpr int SJ = 16 * JTL;
     // NWV wavefronts x 16 IT samples: 4 x 32 (two sample tiles per wavefront) or 8 x 16 (one: half
     // the accumulators, twice the wavefronts per SIMD)
-    static_assert(NWV == 4 || NWV == 8, "4 or 8 wavefronts");
-    constexpr int IT = 8 / NWV, WS = 16 * IT;
+    // SPLIT = 2 (small sample counts: fewer than ~4 workgroups per CU): a 128-sample bucket is done by
+    // two workgroups of 4 x 16 samples that share its candidate list -- half the serial chain per
+    // workgroup, twice the workgroups to balance over the CUs
+    static_assert((NWV == 4 || NWV == 8) && (SPLIT == 1 || (SPLIT == 2 && NWV == 4)), "4 or 8 wavefronts");
+    constexpr int IT = 8 / (NWV * SPLIT), WS = 16 * IT, RW = 128 / SPLIT;
     // X tile: 128 rows x KT values, float32 (64-byte rows) or float64 (128-byte rows, laid out like W)
-    constexpr int XROW = KT * (int)sizeof(XT), XCH = XROW / 16, XD = 128 * XROW / 1024 / NWV;
-    constexpr int S_XT = 128 * XROW, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 / 16 KB + 2 JTL KB
+    constexpr int XROW = KT * (int)sizeof(XT), XCH = XROW / 16, XD = RW * XROW / 1024 / NWV;
+    constexpr int S_XT = RW * XROW, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 / 16 KB (SPLIT: half) + 2 JTL KB
 #if SUBSET_EXPERIMENT & 64
     __shared__ __attribute__((aligned(16))) char smem[6 * S_STAGE];  // halves the blocks per CU
 #else
@@ -1652,15 +1655,17 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
 #endif
     // this class's slice of the schedule (2b): entry blockIdx.x of it, nothing beyond its end
     const uint32_t *range = sched_range + 2 * (3 - JTL);
-    if (blockIdx.x >= range[1]) return;
-    const int wg = sched[range[0] + blockIdx.x];
+    const unsigned entry = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
+    if (entry >= range[1]) return;
+    const int wg = sched[range[0] + entry];
     const int cnt = (int)ucount[wg];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 4 waves x 32 samples
     const int lr = lane & 15, lq = lane >> 4;
-    const int64_t p0 = (int64_t)wg * 128;
+    const int64_t p0 = (int64_t)wg * 128 + (int64_t)part * RW;
+    if (p0 >= N) return;  // (the second half of a last, partial bucket)
     const uint16_t *list = ulist + (size_t)wg * ulist_stride;
 
     double xi[IT];
@@ -2233,7 +2238,15 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     }
 #define DBGSOM_SUBSET_W(JTL, NWV_, STREAM)                                                        \
     do {                                                                                          \
-        if (x_dtype == DBGSOM_F32)                                                                \
+        if (exact_split && x_dtype == DBGSOM_F32)                                                 \
+            hipLaunchKernelGGL((subset_exact_kernel<float, JTL, 4, 2>), dim3((unsigned)(2 * f.nb)), dim3(256), 0, STREAM, \
+                               (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
+                               order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
+        else if (exact_split)                                                                     \
+            hipLaunchKernelGGL((subset_exact_kernel<double, JTL, 4, 2>), dim3((unsigned)(2 * f.nb)), dim3(256), 0, STREAM, \
+                               (const double *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
+                               order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
+        else if (x_dtype == DBGSOM_F32)                                                           \
             hipLaunchKernelGGL((subset_exact_kernel<float, JTL, NWV_>), dim3((unsigned)f.nb), dim3(NWV_ * 64), 0, STREAM, \
                                (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
                                order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
@@ -2250,6 +2263,13 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         const char *e = getenv("DBGSOM_EXACT_WAVES");
         return e ? atoi(e) : 84;
     }();
+    // few sample buckets (C2, a rank's share in strong scaling): two 64-sample workgroups per bucket
+    // (DBGSOM_EXACT_SPLIT=0|1 forces).  Measured at C2 (469 buckets): stage 0.164 -> see DESIGN.md
+    static const int split_env = [] {
+        const char *e = getenv("DBGSOM_EXACT_SPLIT");
+        return e ? atoi(e) : -1;
+    }();
+    const bool exact_split = split_env >= 0 ? split_env != 0 : f.nb <= 1024;
     // (two digits: class 3, then classes 2 and 1)
 #define DBGSOM_SUBSET(JTL, STREAM)                                                                \
     do {                                                                                          \

@@ -829,8 +829,10 @@ def test_full_seed_prepass_on_weakly_clustered_data(o):
 
 
 def test_adaptive_digit_planes_settle_on_the_cheaper_sweep(o):
-    """sweep_planes = 0: starts with the one-product sweep; keeps it where the lists stay short
-    (clustered data), moves to three products where the coarse bound marks the whole map."""
+    """sweep_planes = 0: the engine's arm policy (seeds x digit planes, cost model in engine.hip)
+    starts with cheap seeds and the one-product sweep; it stays there where the lists are short
+    (clustered data) and moves to a finer sweep where the coarse bound marks the whole map (a tiny
+    spread around a large mean).  Results are exact under every arm it tries."""
     from dbgsom_amd.backend import HipBackend
 
     rng = np.random.default_rng(3)
@@ -839,22 +841,25 @@ def test_adaptive_digit_planes_settle_on_the_cheaper_sweep(o):
     hop = gi.lattice_hops(rows, cols)
     Xb, _ = gi.blobs_f32(N, d, 77)
     Xu = (rng.uniform(0.45, 0.55, size=(N, d))).astype(np.float32)   # tiny spread around a big mean
-    for X, settle in ((Xb, 0), (Xu, None)):
+    for X, clustered in ((Xb, True), (Xu, False)):
         W = X[rng.choice(N, M, replace=False)].astype(np.float64)
         be = HipBackend(algorithm="filtered").load(X)
         ex = HipBackend(algorithm="exact").load(X)
         assert int(be.sweep_planes) == 0
-        for e in range(5):
+        q = ex.epoch(W, hop, 2.0, 1e-3, "compact", True)
+        for e in range(9):
             r = be.epoch(W, hop, 2.0, 1e-3, "compact", True)
-            q = ex.epoch(W, hop, 2.0, 1e-3, "compact", True)
             assert np.array_equal(r.winners, q.winners) and np.array_equal(r.distances, q.distances)
         used = [entry[2] for entry in be.filter_log]
-        means = {p: m for (_, m, p) in be.filter_log}
+        means = [entry[1] for entry in be.filter_log]
         assert used[0] == 1 and used[-1] == used[-2] and be._get("plane_hold") > 0, used   # settled
-        best = min(means, key=lambda p: be.plane_cost(p, means[p], M))
-        assert used[-1] == best, (used, means)
-        if settle is None:
-            assert used[-1] >= 2, (used, means)
+        if clustered:   # (either seed arm may win on a set this small; the coarse sweep does)
+            assert used[-1] == 1, (used, means)
+        else:
+            assert used[-1] >= 2 and means[-1] < 0.5 * means[0], (used, means)
+        # what it settled on is the cheapest arm it has seen (cost model of the digit planes alone)
+        seen = {p: m for (_, m, p) in be.filter_log[-3:]}
+        assert used[-1] == min(seen, key=lambda p: be.plane_cost(p, seen[p], M))
 
 
 def test_eight_wavefront_sweep_and_prepass_still_agree_with_the_all_pairs_kernel():
