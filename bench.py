@@ -371,9 +371,14 @@ class Harness:
             self.td.barrier()
         self.torch.cuda.synchronize()
 
+    def coll_device(self):
+        """Where the harness's own small collectives live: HBM under RCCL, the host otherwise (the
+        2-rank rehearsal on one GPU runs over gloo: DBGSOM_BENCH_BACKEND=gloo)."""
+        on_gpu = not self.grouped or self.td.get_backend() == "nccl"
+        return self.torch.device("cuda", self.local) if on_gpu else self.torch.device("cpu")
+
     def max_over_ranks(self, seconds):
-        t = self.torch.tensor([seconds], dtype=self.torch.float64,
-                              device=self.torch.device("cuda", self.local))
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.coll_device())
         if self.grouped:
             self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
         return float(t.item())
@@ -529,8 +534,10 @@ def main():
                   f"`python -m torch.distributed.run --nproc-per-node {args.gpus} ...`",
                   file=sys.stderr)
         sys.exit(2)
+    local = local % max(1, torch.cuda.device_count())   # (rehearsal: several ranks on one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    backend = os.environ.get("DBGSOM_BENCH_BACKEND", "nccl")
     # under torch.distributed.run the group is always created (also for one rank: that run is
     # the single-GPU rehearsal of the RCCL path)
     grouped = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
@@ -543,8 +550,11 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-            td.all_reduce(torch.zeros(1, device=device))
+            if backend == "nccl":
+                td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+                td.all_reduce(torch.zeros(1, device=device))
+            else:
+                td.init_process_group(backend, rank=rank, world_size=world)
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
@@ -583,6 +593,7 @@ def main():
     del Xd
     mom[2 * d] = n_gpu
     if grouped:
+        mom = mom.to(h.coll_device())
         td.all_reduce(mom)
     nn = float(mom[2 * d].item())
     var = mom[d:2 * d] / nn - (mom[:d] / nn) ** 2
@@ -593,6 +604,7 @@ def main():
         sel = torch.randperm(n_gpu, device=device, generator=g)[:M]
         ctl[:] = X[sel].double().reshape(-1)
     if grouped:
+        ctl = ctl.to(h.coll_device())
         td.broadcast(ctl, 0)
     W0 = ctl.reshape(M, d).cpu().numpy()
     hop = lattice_hops(rows, cols)

@@ -186,6 +186,33 @@ def test_bench_under_torchrun_single_rank_rccl():
     assert js["n_gpus"] == 1 and js["value"] > 0 and js["roofline"]["frac"] > 0
 
 
+def test_bench_two_ranks_strong_scaling_rehearsal_on_one_gpu():
+    """The N > 1 path of bench.py (strong scaling: the workload's rows split over the ranks, the
+    per-epoch all-reduce, the weak-scaling rate of the same run, one JSON line from rank 0) with two
+    ranks on the one GPU of a test box: gloo instead of RCCL (DBGSOM_BENCH_BACKEND), everything else
+    as the driver launches it."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DBGSOM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "c2", "--fine-phase", "0"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["scaling"] == "strong" and js["value"] > 0
+    assert js["config"]["samples_total"] == 60_000 and js["config"]["samples_per_gpu"] == 30_000
+    assert js["weak_scaling_same_run"]["samples_per_gpu"] == 60_000
+    assert js["exact"]["prototypes_identical_to_headline"] is True
+    assert "cpu_baseline" not in js and js["roofline"]["frac"] > 0
+
+
 def test_full_size_c3_and_c2_properties():
     """BASELINE configs C3 (N=1e6, d=128, M=2025) and C2 (60k x 784, M=506) at full size:
     oracle spot check + conservation."""
