@@ -17,7 +17,11 @@
 namespace dbgsom {
 
 constexpr int AT = 256;          // threads per workgroup
-constexpr int HS = 2048;         // samples per histogram / scatter workgroup
+// samples per histogram / scatter workgroup: the scatter walks its samples 64 per round, one
+// dependent round after the other -- 2048 samples are 32 rounds (fine when there are thousands of
+// workgroups), a small sample set (C2, a rank's share in strong scaling) gets 512 = 8 rounds and
+// four times the workgroups (scatter_kernel 19 -> see DESIGN.md).  A function of N alone.
+static int hs_for(int64_t N) { return N <= 300000 ? 512 : 2048; }
 constexpr int CH = 128;          // rows per segmented-sum chunk
 
 struct AccWs {
@@ -41,6 +45,7 @@ static int finalize_groups(int64_t M) {
 }
 
 static size_t carve(AccWs *w, char *base, int64_t N, int64_t d, int64_t M) {
+    const int HS = hs_for(N);
     const int64_t nb = (N + HS - 1) / HS;
     const int64_t maxchunks = (N + CH - 1) / CH + M;
     size_t off = 0;
@@ -77,7 +82,7 @@ size_t accumulate_workspace_bytes(int64_t N, int64_t d, int64_t M) {
 __global__ __launch_bounds__(AT) void hist_kernel(const int64_t *__restrict__ win, int64_t N,
                                                   int M, uint32_t *__restrict__ blk,
                                                   int32_t *__restrict__ status,
-                                                  uint32_t *__restrict__ ticket) {
+                                                  uint32_t *__restrict__ ticket, int HS) {
     extern __shared__ uint32_t h[];
     if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;  // of the scan kernel that follows
     for (int j = threadIdx.x; j < M; j += AT) h[j] = 0;
@@ -188,6 +193,7 @@ __global__ __launch_bounds__(CS_COLS * CS_GROUPS) void scan_kernel(uint32_t *__r
 // lanes that agree in every bit), the first of them moves the neuron's write position on: no
 // search through the round's keys, no barrier between wavefronts.
 constexpr int SCW = 64;
+template <int HS>
 __global__ __launch_bounds__(SCW) void scatter_kernel(const int64_t *__restrict__ win, int64_t N,
                                                       int M, int nbits,
                                                       const uint32_t *__restrict__ blk,
@@ -405,12 +411,31 @@ static int key_bits(int64_t M) {  // bits that tell the keys 0 .. M - 1 apart
 // Stable bucket order of the samples by winner, on its own (the filtered BMU search visits the
 // samples in this order).  `ws` needs bucket_sort_workspace_bytes(N, M); `order` gets N int32.
 size_t bucket_sort_workspace_bytes(int64_t N, int64_t M) {
+    const int HS = hs_for(N);
     const int64_t nb = (N + HS - 1) / HS;
     return align_up((size_t)nb * M * 4) + align_up((size_t)M * 4) + 2 * align_up((size_t)(M + 1) * 4) + 256;
 }
 
+// where launch_bucket_sort leaves the exclusive segment starts (M + 1 entries) in its workspace
+const uint32_t *bucket_sort_seg_start(const void *ws, int64_t N, int64_t M) {
+    const int HS = hs_for(N);
+    const int64_t nb = (N + HS - 1) / HS;
+    return reinterpret_cast<const uint32_t *>((const char *)ws + align_up((size_t)nb * M * 4) + align_up((size_t)M * 4));
+}
+
+static void launch_scatter(const int64_t *idx, int64_t N, int Mi, int64_t nb, const uint32_t *blk,
+                           const uint32_t *seg_start, int32_t *order, hipStream_t s) {
+    if (hs_for(N) == 512)
+        hipLaunchKernelGGL(scatter_kernel<512>, dim3((unsigned)nb), dim3(SCW), (size_t)Mi * 4, s, idx, N, Mi,
+                           key_bits(Mi), blk, seg_start, order);
+    else
+        hipLaunchKernelGGL(scatter_kernel<2048>, dim3((unsigned)nb), dim3(SCW), (size_t)Mi * 4, s, idx, N, Mi,
+                           key_bits(Mi), blk, seg_start, order);
+}
+
 int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order, void *ws,
                        hipStream_t s) {
+    const int HS = hs_for(N);
     const int64_t nb = (N + HS - 1) / HS;
     char *base = (char *)ws;
     uint32_t *blk = (uint32_t *)base;
@@ -424,11 +449,10 @@ int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order,
     uint32_t *ticket = (uint32_t *)base;
     const int Mi = (int)M;
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)nb), dim3(AT), (size_t)M * 4, s, idx, N, Mi, blk,
-                       (int32_t *)nullptr, ticket);
+                       (int32_t *)nullptr, ticket, HS);
     hipLaunchKernelGGL(scan_kernel, dim3((unsigned)((M + CS_COLS - 1) / CS_COLS)),
                        dim3(CS_COLS * CS_GROUPS), 0, s, blk, nb, Mi, count, seg_start, chunk_pre, ticket);
-    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nb), dim3(SCW), (size_t)M * 4, s, idx, N, Mi,
-                       key_bits(M), blk, seg_start, order);
+    launch_scatter(idx, N, Mi, nb, blk, seg_start, order, s);
     return launch_status("bucket sort kernels");
 }
 
@@ -459,12 +483,11 @@ static int accumulate_impl(const void *X, int x_dtype, int64_t N, int64_t d, int
     const int Mi = (int)M, di = (int)d;
 
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)w.nb), dim3(AT), (size_t)M * 4, s, idx, N, Mi,
-                       w.blk, status, w.ticket);
+                       w.blk, status, w.ticket, hs_for(N));
     hipLaunchKernelGGL(scan_kernel, dim3((unsigned)((M + CS_COLS - 1) / CS_COLS)),
                        dim3(CS_COLS * CS_GROUPS), 0, s, w.blk, w.nb, Mi, w.count, w.seg_start, w.chunk_pre,
                        w.ticket);
-    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)w.nb), dim3(SCW), (size_t)M * 4, s,
-                       idx, N, Mi, key_bits(M), w.blk, w.seg_start, w.order);
+    launch_scatter(idx, N, Mi, w.nb, w.blk, w.seg_start, w.order, s);
 
     const size_t xe = dtype_size(x_dtype);
     const bool al16 = is_aligned(X, 16) && ((ldx * xe) % 16 == 0);

@@ -105,6 +105,7 @@ int launch_accumulate_epoch(const void *X, int x_dtype, int64_t N, int64_t d, in
 size_t bucket_sort_workspace_bytes(int64_t N, int64_t M);
 int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order, void *ws,
                        hipStream_t s);
+const uint32_t *bucket_sort_seg_start(const void *ws, int64_t N, int64_t M);
 size_t smooth_workspace_bytes(int64_t M, int64_t d);
 int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, double sigma,
                   int layout, const double *W_old, double *W_new, double *change_total, void *ws,

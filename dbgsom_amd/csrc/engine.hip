@@ -1223,10 +1223,7 @@ int dbgsom_ctx_partition(dbgsom_ctx *c, const double *W_host, int64_t M, int rou
     TRY(c->part_ws.reserve(bucket_sort_workspace_bytes(s.N, M)));
     TRY(c->part_counts.reserve((size_t)(M + 1) * 8));
     TRY(launch_bucket_sort(c->qidx.as<int64_t>(), s.N, M, c->part_order.as<int32_t>(), c->part_ws.p, c->stream));
-    // launch_bucket_sort's workspace: [blk | count (M u32) | seg_start (M + 1 u32) | ...]
-    const int64_t nbh = (s.N + 2047) / 2048;
-    const uint32_t *seg_start = reinterpret_cast<const uint32_t *>(c->part_ws.as<char>() + align_up((size_t)nbh * M * 4) +
-                                                                  align_up((size_t)M * 4));
+    const uint32_t *seg_start = bucket_sort_seg_start(c->part_ws.p, s.N, M);
     hipLaunchKernelGGL(seg_counts_kernel, dim3(grid1d(M)), dim3(256), 0, c->stream, seg_start, M, s.N, c->part_counts.as<int64_t>());
     TRY(launch_status("seg_counts_kernel"));
     DBGSOM_HIP_CHECK(hipMemcpyAsync(counts_host, c->part_counts.p, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1245,9 +1242,7 @@ int dbgsom_ctx_subset_create(dbgsom_ctx *c, int64_t neuron, dbgsom_ctx **child_o
     if (!c->part_valid) { set_error("dbgsom_ctx_subset_create: call dbgsom_ctx_partition first"); return DBGSOM_ESTATE; }
     DBGSOM_REQUIRE(neuron >= 0 && neuron < c->partM, "neuron out of range");
     Samples &s = c->xs;
-    const int64_t nbh = (s.N + 2047) / 2048;
-    const uint32_t *seg_start = reinterpret_cast<const uint32_t *>(c->part_ws.as<char>() + align_up((size_t)nbh * c->partM * 4) +
-                                                                  align_up((size_t)c->partM * 4));
+    const uint32_t *seg_start = bucket_sort_seg_start(c->part_ws.p, s.N, c->partM);
     uint32_t seg[2] = {0, 0};
     DBGSOM_HIP_CHECK(hipMemcpyAsync(&seg[0], seg_start + neuron, 4, hipMemcpyDeviceToHost, c->stream));
     if (neuron + 1 < c->partM)
