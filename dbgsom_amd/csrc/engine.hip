@@ -74,12 +74,14 @@ struct PinBuf {
         if (bytes <= cap) return DBGSOM_OK;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         const size_t want = align_up(bytes * 2, 4096);
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return DBGSOM_ENOMEM; }
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&dev, p, 0);
+        if (e != hipSuccess) { if (p) (void)hipHostFree(p); p = nullptr; dev = nullptr; (void)hipGetLastError(); set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return DBGSOM_ENOMEM; }
         cap = want;
         return DBGSOM_OK;
     }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    void *dev = nullptr;  // the same memory as the GPU addresses it (kernels write results straight into it)
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -107,6 +109,21 @@ __global__ void f64_to_f32_kernel(const double *__restrict__ in, float *__restri
 __global__ void u64_to_f64_kernel(const unsigned long long *__restrict__ in, double *__restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (double)in[i];
+}
+// The epoch's small results in ONE kernel straight into page-locked host memory (no copy engine
+// round trips behind the last kernel: four queued D2H copies cost ~30 us per epoch):
+// out = [a (M) | E (M) | change_total | status | sum of candidate-list lengths]
+__global__ void pack_results_kernel(const double *__restrict__ aE, int64_t M, const double *__restrict__ chg,
+                                    const double *__restrict__ status, const unsigned long long *__restrict__ list_sum,
+                                    double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * M; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = aE[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[2 * M] = chg[0];
+        out[2 * M + 1] = status[0];
+        out[2 * M + 2] = list_sum ? (double)list_sum[0] : 0.0;
+    }
+    __threadfence_system();
 }
 __global__ void status_to_f64_kernel(const int32_t *__restrict__ status, double *__restrict__ out) {
     out[0] = status[0] ? 1.0 : 0.0;
@@ -150,6 +167,7 @@ using namespace dbgsom;
 
 // the device-level ABI the engine drives (defined in filter.hip / stats.hip)
 extern "C" {
+const unsigned long long *dbgsom_filter_count_sum_ptr(const void *workspace_dev, int64_t N, int64_t d, int64_t M);
 size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d);
 size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M);
 }
@@ -470,11 +488,9 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
 }
 
 // after an epoch has completed: look at how long the candidate lists were, decide what comes next
-void update_policy(dbgsom_ctx *c, const uint32_t *counts, int64_t nb, int64_t M) {
+void update_policy(dbgsom_ctx *c, double list_sum, int64_t nb, int64_t M) {
     if (!c->last_filtered) { c->last_mean = NAN; return; }
-    double sum = 0.0;
-    for (int64_t b = 0; b < nb; ++b) sum += counts[b];
-    const double mean = nb ? sum / (double)nb : 0.0;
+    const double mean = nb ? list_sum / (double)nb : 0.0;
     c->last_mean = mean;
     adapt_arms(c, mean, M);
     if (c->algorithm == DBGSOM_ALG_AUTO) {
@@ -566,18 +582,16 @@ int smooth_and_fetch(dbgsom_ctx *c, int64_t M, double sigma, int layout, int fla
     TRY(launch_smooth(sums, M, dp, c->hop.as<float>(), sigma, layout, c->Wb[c->cur].as<double>(),
                       c->Wb[nxt].as<double>(), chg, c->sm_ws.p, c->sm_ws.cap, c->stream));
     mark(c, 3);
-    // the epoch's small results come back in ONE round trip: queued copies into pinned memory, one
-    // stream synchronisation
-    const int64_t nb = (s.N + 127) / 128;
-    TRY(c->tail.reserve((size_t)(2 * M + 2) * 8));
+    // the epoch's small results: one kernel writes them into mapped page-locked memory, one stream
+    // synchronisation
+    TRY(c->tail.reserve((size_t)(2 * M + 3) * 8));
     double *tail = c->tail.as<double>();
-    DBGSOM_HIP_CHECK(hipMemcpyAsync(tail, sums + (size_t)M * dp + M, (size_t)2 * M * 8, hipMemcpyDeviceToHost, c->stream));
-    DBGSOM_HIP_CHECK(hipMemcpyAsync(tail + 2 * M, chg, 8, hipMemcpyDeviceToHost, c->stream));
-    DBGSOM_HIP_CHECK(hipMemcpyAsync(tail + 2 * M + 1, sums + (size_t)M * (dp + 3), 8, hipMemcpyDeviceToHost, c->stream));
-    if (c->last_filtered) {
-        TRY(c->counts.reserve((size_t)nb * 4));
-        TRY(dbgsom_bmu_filtered_counts_async(c->filt_ws.p, s.N, dp, M, c->counts.as<uint32_t>(), nb, c->stream));
-    }
+    const unsigned long long *list_sum =
+        c->last_filtered ? dbgsom_filter_count_sum_ptr(c->filt_ws.p, s.N, dp, M) : nullptr;
+    hipLaunchKernelGGL(pack_results_kernel, dim3((unsigned)((2 * M + 255) / 256 < 64 ? (2 * M + 255) / 256 : 64)), dim3(256), 0,
+                       c->stream, sums + (size_t)M * dp + M, M, chg, sums + (size_t)M * (dp + 3), list_sum,
+                       reinterpret_cast<double *>(c->tail.dev));
+    TRY(launch_status("pack_results_kernel"));
     if (W_new_host) {
         TRY(download_unpadded(c, W_new_host, c->Wb[nxt].p, M, d, dp, 8));
         ++c->w_down_calls; c->w_down_bytes += M * d * 8;
@@ -1023,7 +1037,7 @@ int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f
         rc = smooth_and_fetch(c, M, sigma, layout, flags, W_new_host, change_total_host, errors_host, activations_host,
                               idx, idx_host, dist_host);
         if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) break;
-        update_policy(c, c->counts.as<uint32_t>(), (s.N + 127) / 128, M);
+        update_policy(c, c->tail.as<double>()[2 * M + 2], (s.N + 127) / 128, M);
     } while (0);
     if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) { (void)hipStreamSynchronize(c->stream); c->hint_valid = false; }
     return rc;

@@ -32,7 +32,8 @@ constexpr int FNT = 512;          // threads per sweep workgroup (8 wavefronts)
 constexpr int FSTAGES = 3;
 constexpr int PREPASS_KTILES = 3;  // k-tiles the seed pre-pass samples (tile_select_kernel picks them)
 constexpr int SCHED_BINS = 16;     // launch-order bins of the exact stage (section 2b)
-constexpr int SCHED_CTR = 2 * SCHED_BINS + 8;  // bin counts | cursors | [start, n] of classes 3, 2, 1
+constexpr int SCHED_CTR = 2 * SCHED_BINS + 8;  // bin counts | cursors | [start, n] of classes 3, 2, 1 | sum of list lengths (u64)
+constexpr int SCHED_SUM = 2 * SCHED_BINS + 6;  // (8-byte aligned: the counters sit on a 256-byte boundary)
 constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
 #ifndef SUBSET_EXPERIMENT
 // Diagnostic builds of this file (never the shipped library): -DSUBSET_EXPERIMENT=<bits> /
@@ -1021,6 +1022,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         if (lane == 0) {
             ucount[blockIdx.x] = base;
             atomicAdd(&sched_ctr[sched_bin(base)], 1u);  // bin counts of the exact stage's schedule (2b)
+            // sum of the list lengths (what the engine's policy looks at: 8 bytes D2H instead of nb x 4)
+            atomicAdd(reinterpret_cast<unsigned long long *>(sched_ctr + SCHED_SUM), (unsigned long long)base);
         }
 #if SWEEP_EXPERIMENT & 512
         if (lane == 0) reinterpret_cast<unsigned *>(out + 512)[0] = (unsigned)misc[3];
@@ -1568,6 +1571,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
         if (lane == 0) {
             ucount[blockIdx.x] = base;
             atomicAdd(&sched_ctr[sched_bin(base)], 1u);  // bin counts of the exact stage's schedule (2b)
+            // sum of the list lengths (what the engine's policy looks at: 8 bytes D2H instead of nb x 4)
+            atomicAdd(reinterpret_cast<unsigned long long *>(sched_ctr + SCHED_SUM), (unsigned long long)base);
         }
 #if SWEEP_EXPERIMENT & 1024
         {   // stamps of the four waves behind the list: uint32 at uint16 offset 512 of this row
@@ -2302,6 +2307,13 @@ size_t dbgsom_debug_ulist_offset(int64_t N, int64_t d, int64_t M) {
     return (size_t)((char *)f.ulist - (char *)nullptr);
 }
 #endif
+
+/* (internal, engine.hip) device address of the sum of the candidate-list lengths of the last call */
+const unsigned long long *dbgsom_filter_count_sum_ptr(const void *workspace_dev, int64_t N, int64_t d, int64_t M) {
+    FilterWs f;
+    carve_filter(&f, (char *)const_cast<void *>(workspace_dev), N, d, M);
+    return reinterpret_cast<const unsigned long long *>(f.sched_ctr + SCHED_SUM);
+}
 
 /* diagnostics: sizes of the per-workgroup candidate lists of the last dbgsom_bmu_filtered call */
 int dbgsom_bmu_filtered_counts(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
