@@ -440,15 +440,15 @@ def fine_phase_regime(h, X, W0, M, hop, gamma, n_total):
 
     sig0, sig1 = 0.2 * np.sqrt(M), max(0.7, 0.05 * np.sqrt(M))
     schedule = [sig1 + (sig0 - sig1) * np.exp(-0.35 * e) for e in range(14)]
-    out = {"sigma": sig1, "warmup_epochs": len(schedule), "centres_layout": "aligned"}
+    out = {"sigma": sig1, "warmup_epochs": len(schedule) + 24, "centres_layout": "aligned"}
     final = {}
     for algo in ("exact", "auto"):
         be = HipBackend(h.local, algorithm=algo)
         be._set("timing", 1)
         be.load_device(X)
         be.set_weights(W0)
-        for s_ in schedule:  # untimed: organise the map
-            be.epoch(RESIDENT, hop, s_, gamma, "aligned", False, keep_on_device=True)
+        for s_ in schedule + [sig1] * 24:  # untimed: organise the map, then let it (and the search
+            be.epoch(RESIDENT, hop, s_, gamma, "aligned", False, keep_on_device=True)  # policy) settle
         state = {}
 
         def step():

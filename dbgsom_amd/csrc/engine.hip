@@ -177,7 +177,10 @@ namespace {
 constexpr int64_t FILTER_MIN_PROTOTYPES = 129;  // at or below 128 one chunk of the all-pairs kernel is cheaper (measured)
 constexpr int64_t FILTER_MAX_FEATURES = 43690;  // int32 digit-product accumulators: 3 x 128 x 128 x d < 2^31
 constexpr int FILTER_BACKOFF = 8;
-constexpr int PLANES_REPROBE = 64;
+// epochs an arm is kept before its alternatives get another look: a map in training changes (early,
+// nearly collapsed maps want a fine sweep, organised ones the coarse one), and only running an arm
+// tells how long its lists are; a look costs one epoch of an arm that could at best be cheaper
+constexpr int PLANES_REPROBE = 16;
 // cost model of the candidate sweep (per prototype, in units of the three-product sweep) against a
 // list entry of the exact stage -- measured at C4 with this build's kernels: one product 1.00 ms,
 // three 2.87 ms per 1024 prototypes; exact stage 1.16 ms per 33 list entries
