@@ -239,6 +239,7 @@ struct dbgsom_ctx {
     int planes_next = 1, planes_used = 1;
     int64_t planeM = -1;
     double arm_known[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};  // [seeds][planes]
+    int arm_age[3][4] = {};   // epochs since the arm last ran
     int plane_hold = 0;
     int seed_mode = 0;   // stateless seeds: 0 = the cheap pre-pass, 1 = the full one
     double best_mean = NAN;  // list length of the cheapest known arm (what the back-off looks at)
@@ -438,17 +439,26 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
         for (auto &r : c->arm_known) for (double &k : r) k = NAN;
         c->plane_hold = 0;
     }
+    static const double SEED_COST[3] = {1.15, 2.0, 1.0};
+    auto fixed = [&](int s_, int q) { return SEED_COST[s_] * SWEEP_COST[q] * (double)M; };
+    for (auto &r : c->arm_age) for (int &a : r) ++a;
     c->arm_known[row][p] = mean;
+    c->arm_age[row][p] = 0;
     if (c->plane_hold > 0) {
         c->best_mean = mean;
-        if (--c->plane_hold == 0) {  // forget the alternatives, they get another look
-            for (auto &r : c->arm_known) for (double &k : r) k = NAN;
-            c->arm_known[row][p] = mean;
+        if (--c->plane_hold == 0) {
+            // The alternatives get another look -- the cheap ones.  An arm whose sweep / pre-pass
+            // costs LESS than the current one is forgotten (looking at it again is one epoch that
+            // can only be dearer by its lists); a dearer one keeps its last result for 128 epochs
+            // (a look at the full pre-pass is a whole extra sweep: every 16 epochs that was 6 % of
+            // the C5 shard's time).
+            for (int s_ = 0; s_ < 3; ++s_)
+                for (int q = 1; q <= 3; ++q)
+                    if (!(s_ == row && q == p) && (fixed(s_, q) < fixed(row, p) || c->arm_age[s_][q] >= 128))
+                        c->arm_known[s_][q] = NAN;
         }
         return;
     }
-    static const double SEED_COST[3] = {1.15, 2.0, 1.0};
-    auto fixed = [&](int s_, int q) { return SEED_COST[s_] * SWEEP_COST[q] * (double)M; };
     auto allowed = [&](int s_, int q) {
         if (c->sweep_planes && q != c->sweep_planes) return false;        // planes fixed by the caller
         if (row == 2) return s_ == 2;                                      // hinted: only the planes vary
