@@ -447,15 +447,20 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
     if (c->plane_hold > 0) {
         c->best_mean = mean;
         if (--c->plane_hold == 0) {
-            // The alternatives get another look -- the cheap ones.  An arm whose sweep / pre-pass
-            // costs LESS than the current one is forgotten (looking at it again is one epoch that
-            // can only be dearer by its lists); a dearer one keeps its last result for 128 epochs
-            // (a look at the full pre-pass is a whole extra sweep: every 16 epochs that was 6 % of
-            // the C5 shard's time).
+            // The alternatives get another look -- the cheap and plausible ones.  An arm whose sweep /
+            // pre-pass costs LESS than the current one and whose last result was within 3x of the
+            // current cost is forgotten (looking at it again is one epoch that can only be dearer by
+            // its lists); every other arm keeps its last result for 128 epochs (a look at the full
+            // pre-pass is a whole extra sweep: every 16 epochs that was 6 % of the C5 shard's time;
+            // a look at the one-product sweep on isotropic data is a 1024-candidate exact stage).
+            const double now = fixed(row, p) + LIST_COST * mean;
             for (int s_ = 0; s_ < 3; ++s_)
-                for (int q = 1; q <= 3; ++q)
-                    if (!(s_ == row && q == p) && (fixed(s_, q) < fixed(row, p) || c->arm_age[s_][q] >= 128))
+                for (int q = 1; q <= 3; ++q) {
+                    if ((s_ == row && q == p) || isnan(c->arm_known[s_][q])) continue;
+                    const double then = fixed(s_, q) + LIST_COST * c->arm_known[s_][q];
+                    if ((fixed(s_, q) < fixed(row, p) && then <= 3.0 * now) || c->arm_age[s_][q] >= 128)
                         c->arm_known[s_][q] = NAN;
+                }
         }
         return;
     }
