@@ -239,7 +239,10 @@ struct dbgsom_ctx {
     int planes_next = 1, planes_used = 1;
     int64_t planeM = -1;
     double arm_known[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};  // [seeds][planes]
-    int arm_age[3][4] = {};   // epochs since the arm last ran
+    double arm_seen[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};   // last result ever
+    int arm_age[3][4] = {};   // updates of the map since the arm last ran
+    int arm_wait[3][4] = {{16, 16, 16, 16}, {16, 16, 16, 16}, {16, 16, 16, 16}};
+    bool last_frozen = false;
     int plane_hold = 0;
     int seed_mode = 0;   // stateless seeds: 0 = the cheap pre-pass, 1 = the full one
     double best_mean = NAN;  // list length of the cheapest known arm (what the back-off looks at)
@@ -437,29 +440,31 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
     if (c->planeM != M) {  // another map size: what was learnt no longer applies
         c->planeM = M;
         for (auto &r : c->arm_known) for (double &k : r) k = NAN;
+        for (auto &r : c->arm_seen) for (double &k : r) k = NAN;
+        for (auto &r : c->arm_wait) for (int &k : r) k = 16;
         c->plane_hold = 0;
     }
     static const double SEED_COST[3] = {1.15, 2.0, 1.0};
     auto fixed = [&](int s_, int q) { return SEED_COST[s_] * SWEEP_COST[q] * (double)M; };
-    for (auto &r : c->arm_age) for (int &a : r) ++a;
-    c->arm_known[row][p] = mean;
+    // an arm's age = how often the map has been UPDATED since it ran (a frozen map -- the bench, a
+    // series of queries -- does not age what is known about it)
+    if (!c->last_frozen)
+        for (auto &r : c->arm_age) for (int &a : r) ++a;
+    const bool remeasured = !isnan(c->arm_seen[row][p]);
+    c->arm_known[row][p] = c->arm_seen[row][p] = mean;
     c->arm_age[row][p] = 0;
     if (c->plane_hold > 0) {
         c->best_mean = mean;
         if (--c->plane_hold == 0) {
-            // The alternatives get another look -- the cheap and plausible ones.  An arm whose sweep /
-            // pre-pass costs LESS than the current one and whose last result was within 3x of the
-            // current cost is forgotten (looking at it again is one epoch that can only be dearer by
-            // its lists); every other arm keeps its last result for 128 epochs (a look at the full
-            // pre-pass is a whole extra sweep: every 16 epochs that was 6 % of the C5 shard's time;
-            // a look at the one-product sweep on isotropic data is a 1024-candidate exact stage).
-            const double now = fixed(row, p) + LIST_COST * mean;
+            // The alternatives get another look once the map has moved on: an arm whose sweep /
+            // pre-pass costs LESS than the current one after arm_wait (16, doubling up to 128 every
+            // time the look does not pay) updates of the map -- one epoch that can only be dearer by
+            // its lists; a dearer arm after 128 (a look at the full pre-pass is a whole extra sweep).
             for (int s_ = 0; s_ < 3; ++s_)
                 for (int q = 1; q <= 3; ++q) {
                     if ((s_ == row && q == p) || isnan(c->arm_known[s_][q])) continue;
-                    const double then = fixed(s_, q) + LIST_COST * c->arm_known[s_][q];
-                    if ((fixed(s_, q) < fixed(row, p) && then <= 3.0 * now) || c->arm_age[s_][q] >= 128)
-                        c->arm_known[s_][q] = NAN;
+                    const int wait = fixed(s_, q) < fixed(row, p) ? c->arm_wait[s_][q] : 128;
+                    if (c->arm_age[s_][q] >= wait) c->arm_known[s_][q] = NAN;
                 }
         }
         return;
@@ -495,6 +500,8 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
         consider(bs, bp + 1); consider(bs, bp - 1);
         if (bs != 2) consider(1 - bs, bp);
     }
+    if (remeasured)  // a second look at this arm: did it pay?
+        c->arm_wait[row][p] = (bs == row && bp == p) ? 16 : (c->arm_wait[row][p] >= 64 ? 128 : 2 * c->arm_wait[row][p]);
     if (es >= 0) {
         c->seed_mode = es == 1 ? 1 : 0;
         c->planes_next = ep;
@@ -1055,6 +1062,7 @@ int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f
         rc = smooth_and_fetch(c, M, sigma, layout, flags, W_new_host, change_total_host, errors_host, activations_host,
                               idx, idx_host, dist_host);
         if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) break;
+        c->last_frozen = (flags & DBGSOM_EPOCH_FROZEN) != 0;
         update_policy(c, c->tail.as<double>()[2 * M + 2], (s.N + 127) / 128, M);
     } while (0);
     if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) { (void)hipStreamSynchronize(c->stream); c->hint_valid = false; }
