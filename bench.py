@@ -307,7 +307,7 @@ def run_via_ctx(args):
         Wn = {}
         for algo in dict.fromkeys([args.algorithm, "exact"]):
             nat.call("dbgsom_ctx_set_option", ctx, b"algorithm", nat.ALGORITHMS[algo])
-            nat.call("dbgsom_ctx_set_option", ctx, b"timing", 1)
+            nat.call("dbgsom_ctx_set_option", ctx, b"timing", 0)   # the timed steps run un-instrumented
             nat.call("dbgsom_ctx_set_weights", ctx, W0.ctypes.data, M)
 
             def step():
@@ -322,7 +322,8 @@ def run_via_ctx(args):
             for _ in range(args.steps):
                 step()
             elapsed = time.perf_counter() - t0
-            for _ in range(3):   # phase times from three more (untimed) steps
+            nat.call("dbgsom_ctx_set_option", ctx, b"timing", 1)
+            for _ in range(3):   # phase times from three more (untimed) steps with HIP events
                 step()
                 nat.call("dbgsom_ctx_phase_ms", ctx, ms)
                 acc += np.array(list(ms)) / 3
@@ -384,19 +385,26 @@ class Harness:
         return float(t.item())
 
     def timed_epochs(self, be, step_fn, warmup, steps):
-        """W untimed steps, then exactly `steps` timed ones bracketed by barrier + synchronize;
-        returns (max-over-ranks seconds, per-phase mean ms from HIP events on the launch stream)."""
+        """W untimed steps, then exactly `steps` timed ones bracketed by barrier + synchronize, with
+        the context's event instrumentation OFF (ten event records per epoch are worth 2-5 % at small
+        shapes); then min(steps, 5) more steps, untimed, with it ON for the per-phase HIP-event
+        times (events on the context's stream).  Returns (max-over-ranks seconds, mean ms per phase)."""
         be.phase_log = None
+        be._set("timing", 0)
         for _ in range(warmup):
             step_fn()
-        be.phase_log = []
         self.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             step_fn()
         self.sync()
         elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        be._set("timing", 1)
+        be.phase_log = []
+        for _ in range(min(steps, 5)):
+            step_fn()
         log, be.phase_log = np.array(be.phase_log), None
+        be._set("timing", 0)
         return elapsed, dict(zip(PHASES, log.mean(axis=0).tolist()))
 
 
@@ -406,7 +414,6 @@ def frozen_map_regime(h, algorithm, X, W0, hop, sigma, gamma, steps=None, warmup
     from dbgsom_amd.backend import RESIDENT, HipBackend
 
     be = HipBackend(h.local, algorithm=algorithm)
-    be._set("timing", 1)
     be.load_device(X)
     be.set_weights(W0)
     M = W0.shape[0]
@@ -444,7 +451,6 @@ def fine_phase_regime(h, X, W0, M, hop, gamma, n_total):
     final = {}
     for algo in ("exact", "auto"):
         be = HipBackend(h.local, algorithm=algo)
-        be._set("timing", 1)
         be.load_device(X)
         be.set_weights(W0)
         for s_ in schedule + [sig1] * 24:  # untimed: organise the map, then let it (and the search

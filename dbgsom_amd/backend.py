@@ -533,7 +533,7 @@ class HipBackend(HotPathBackend):
         elif self.algorithm != "exact":
             self.filter_log.append(("exact", None))
         del self.filter_log[:-64]
-        if self.phase_log is not None:
+        if self.phase_log is not None:   # (needs the context option "timing")
             ms = (ctypes.c_double * 8)()
             _native.call("dbgsom_ctx_phase_ms", self._ctx, ms)
             self.phase_log.append([float(v) for v in ms])
