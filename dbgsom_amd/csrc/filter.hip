@@ -2234,7 +2234,13 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     // on a second stream forked from the caller's), so that the tail of one launch -- a few long
     // lists on a mostly idle chip -- overlaps the others
     SideStream &side = g_side;
-    const bool fork = side.ready();
+    // (measured also for few buckets, where the fork and join cost ~20 us of bubbles: C2 0.168 -> 0.123
+    // ms for the stage, a 125 k-row shard of C4 0.303 -> 0.265; DBGSOM_EXACT_FORK=0 runs them in a row)
+    static const int fork_env = [] {
+        const char *e = getenv("DBGSOM_EXACT_FORK");
+        return e ? atoi(e) : 1;
+    }();
+    const bool fork = fork_env != 0 && side.ready();
     hipStream_t s2 = fork ? side.stream : s, s3 = fork ? side.stream2 : s;
     if (fork) {
         DBGSOM_HIP_CHECK(hipEventRecord(side.forked, s));
