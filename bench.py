@@ -225,7 +225,17 @@ def rooflines(workload, n, d, M, xbytes, ph, planes, counts):
     achieved = ALGORITHMIC work of one launch / its HIP-event duration in this run."""
     flops = 2.0 * n * M * d
     out = []
-    if ph["sweep"] > 0:
+    if ph["sweep"] > 0 and planes == 0:
+        # no sweep: candidates from the triangle inequality -- one pass over two digit planes of X
+        # (the seed distances) and an M x M matrix of prototype gaps; HBM-bound
+        gbps = 2.0 * n * d / (ph["sweep"] * 1e-3) / 1e9
+        traffic, src = measured_traffic(workload, "prune")
+        out.append({"stage": "candidates by triangle inequality (no sweep)",
+                    "kernel": "proto_gap_kernel + prune_mark_kernel", "bound": "hbm", "dtype": "i8",
+                    "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                    "kernel_ms": ph["sweep"], "traffic": traffic, "traffic_source": src,
+                    "algorithmic_bytes": 2.0 * n * d})
+    elif ph["sweep"] > 0:
         ops = flops * SWEEP_PRODUCTS[planes]     # int8 multiply-adds x 2 on the d real features
         ach = ops / (ph["sweep"] * 1e-3) / 1e12
         kern = SWEEP_KERNEL[planes]

@@ -112,7 +112,7 @@ __global__ void u64_to_f64_kernel(const unsigned long long *__restrict__ in, dou
 }
 // The epoch's small results in ONE kernel straight into page-locked host memory (no copy engine
 // round trips behind the last kernel: four queued D2H copies cost ~30 us per epoch):
-// out = [a (M) | E (M) | change_total | status | sum of candidate-list lengths]
+// out = [a (M) | E (M) | change_total | status | sum of candidate-list lengths | the same of a pruning probe]
 __global__ void pack_results_kernel(const double *__restrict__ aE, int64_t M, const double *__restrict__ chg,
                                     const double *__restrict__ status, const unsigned long long *__restrict__ list_sum,
                                     double *__restrict__ out) {
@@ -122,6 +122,7 @@ __global__ void pack_results_kernel(const double *__restrict__ aE, int64_t M, co
         out[2 * M] = chg[0];
         out[2 * M + 1] = status[0];
         out[2 * M + 2] = list_sum ? (double)list_sum[0] : 0.0;
+        out[2 * M + 3] = list_sum ? (double)list_sum[1] : 0.0;  // (of a counting-only pruning launch)
     }
     __threadfence_system();
 }
@@ -186,6 +187,11 @@ constexpr int PLANES_REPROBE = 16;
 // three 2.87 ms per 1024 prototypes; exact stage 1.16 ms per 33 list entries
 const double SWEEP_COST[4] = {0.0, 0.35, 1.0, 1.96};
 constexpr double LIST_COST = 12.5;
+// arm 0 of the policy: no sweep, candidates from the triangle inequality (filter.hip 2c).  In the same
+// units: one pass over the X plane ~ 170 prototypes of the one-product sweep (C4: 0.17 of 1.0 ms per
+// 1024), plus the M x M gap matrix (three products, a third of the sweep's rate: ~ 9 M / N sweeps)
+constexpr double PRUNE_PASS_COST = 60.0;
+constexpr int64_t PRUNE_MAX_M = 8192;
 
 struct Samples {  // one resident sample set (training samples, or a query batch)
     int dtype = -1;            // storage dtype in HBM
@@ -236,7 +242,9 @@ struct dbgsom_ctx {
     bool part_valid = false;
     // policy
     int filter_backoff = 0, filter_fail = 0;
-    int planes_next = 1, planes_used = 1;
+    int planes_next = 1, planes_used = 1;   // 1 .. 3 digit planes of the sweep; 0 = no sweep (triangle pruning)
+    bool probe_next = false, last_probed = false;  // a counting-only pruning launch beside the sweep
+    double last_probe_mean = NAN;
     int64_t planeM = -1;
     double arm_known[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};  // [seeds][planes]
     double arm_seen[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};   // last result ever
@@ -376,7 +384,16 @@ bool filter_applies(const dbgsom_ctx *c, int64_t M) {
     return filter_shape_ok(c->xs, M);
 }
 
-int planes_for_call(const dbgsom_ctx *c) { return c->sweep_planes ? c->sweep_planes : c->planes_next; }
+// what the next filtered search runs: 1 .. 3 digit planes, 0 = triangle pruning (option value 4)
+int planes_for_call(const dbgsom_ctx *c) {
+    return c->sweep_planes ? (c->sweep_planes == 4 ? 0 : c->sweep_planes) : c->planes_next;
+}
+// the (seed_stride, sweep_planes) arguments of dbgsom_bmu_filtered for arm `planes`
+void filter_call_args(int planes, bool probe, int64_t M, int *stride, int *planes_arg) {
+    *planes_arg = planes ? planes : 1;
+    if (!planes && M <= PRUNE_MAX_M) *stride |= DBGSOM_PRUNE;
+    else if (probe && M <= PRUNE_MAX_M) *stride |= DBGSOM_PRUNE_PROBE;
+}
 
 // prototypes: make W (host, or the resident ones) the consumed matrix Wb[cur]; norms into ww
 int stage_weights(dbgsom_ctx *c, const double *W_host, int64_t M, int64_t d, int64_t dp) {
@@ -401,10 +418,14 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     TRY(ensure_planes(c, s));
     TRY(ws.reserve_zeroed(dbgsom_bmu_filtered_workspace_bytes(s.N, s.dp, M), c->stream));
     c->planes_used = planes_for_call(c);
+    if (c->planes_used == 0 && M > PRUNE_MAX_M) c->planes_used = 1;
     c->last_seed_full = !prev_idx && c->seed_mode == 1 && c->seed_stride == 0;
-    const int stride = c->last_seed_full ? DBGSOM_SEED_FULL : c->seed_stride;
+    int stride = c->last_seed_full ? DBGSOM_SEED_FULL : c->seed_stride, planes_arg = 1;
+    c->last_probed = c->probe_next && c->planes_used != 0 && M <= PRUNE_MAX_M;
+    c->probe_next = false;
+    filter_call_args(c->planes_used, c->last_probed, M, &stride, &planes_arg);
     TRY(dbgsom_bmu_filtered(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), s.planes.p, W, M,
-                            c->ww.as<double>(), prev_idx, order, stride, c->planes_used, round_f32, idx,
+                            c->ww.as<double>(), prev_idx, order, stride, planes_arg, round_f32, idx,
                             dist, ws.p, ws.cap, c->stream));
     c->last_filter_M = M; c->last_filter_N = s.N; c->last_filter_d = s.dp; c->last_filter_ws = ws.p;
     return DBGSOM_OK;
@@ -434,7 +455,7 @@ int run_allreduce(dbgsom_ctx *c, double *buf, int64_t count) {
 // single step leads there (full seeds alone: 1024 candidates, finer planes alone: 981, both: 17).
 // When nothing is left to try it stays for PLANES_REPROBE epochs, then forgets the alternatives.
 // Results never depend on any of this.
-void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
+void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
     const int row = c->last_hinted ? 2 : (c->last_seed_full ? 1 : 0);
     const int p = c->planes_used;
     if (c->planeM != M) {  // another map size: what was learnt no longer applies
@@ -445,7 +466,13 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
         c->plane_hold = 0;
     }
     static const double SEED_COST[3] = {1.15, 2.0, 1.0};
-    auto fixed = [&](int s_, int q) { return SEED_COST[s_] * SWEEP_COST[q] * (double)M; };
+    // (arm 0: the one-product pre-pass, one pass over the X plane and the gap matrix)
+    auto fixed = [&](int s_, int q) {
+        if (q == 0)
+            return (SEED_COST[s_] - 1.0) * SWEEP_COST[1] * (double)M + PRUNE_PASS_COST +
+                   SWEEP_COST[1] * (double)M * 9.0 * (double)M / (double)(N > 0 ? N : 1);
+        return SEED_COST[s_] * SWEEP_COST[q] * (double)M;
+    };
     // an arm's age = how often the map has been UPDATED since it ran (a frozen map -- the bench, a
     // series of queries -- does not age what is known about it)
     if (!c->last_frozen)
@@ -453,6 +480,10 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
     const bool remeasured = !isnan(c->arm_seen[row][p]);
     c->arm_known[row][p] = c->arm_seen[row][p] = mean;
     c->arm_age[row][p] = 0;
+    if (c->last_probed) {  // what arm 0 would have produced from the same seeds
+        c->arm_known[row][0] = c->arm_seen[row][0] = c->last_probe_mean;
+        c->arm_age[row][0] = 0;
+    }
     if (c->plane_hold > 0) {
         c->best_mean = mean;
         if (--c->plane_hold == 0) {
@@ -461,7 +492,7 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
             // time the look does not pay) updates of the map -- one epoch that can only be dearer by
             // its lists; a dearer arm after 128 (a look at the full pre-pass is a whole extra sweep).
             for (int s_ = 0; s_ < 3; ++s_)
-                for (int q = 1; q <= 3; ++q) {
+                for (int q = 0; q <= 3; ++q) {
                     if ((s_ == row && q == p) || isnan(c->arm_known[s_][q])) continue;
                     const int wait = fixed(s_, q) < fixed(row, p) ? c->arm_wait[s_][q] : 128;
                     if (c->arm_age[s_][q] >= wait) c->arm_known[s_][q] = NAN;
@@ -470,14 +501,15 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
         return;
     }
     auto allowed = [&](int s_, int q) {
-        if (c->sweep_planes && q != c->sweep_planes) return false;        // planes fixed by the caller
+        if (c->sweep_planes && q != (c->sweep_planes == 4 ? 0 : c->sweep_planes)) return false;  // fixed by the caller
+        if (q == 0 && M > PRUNE_MAX_M) return false;
         if (row == 2) return s_ == 2;                                      // hinted: only the planes vary
         return s_ == 0 || (s_ == 1 && c->seed_stride == 0);               // a caller's stride: cheap seeds only
     };
     int bs = row, bp = p;
     double bc = fixed(row, p) + LIST_COST * mean;
     for (int s_ = 0; s_ < 3; ++s_)
-        for (int q = 1; q <= 3; ++q)
+        for (int q = 0; q <= 3; ++q)
             if (allowed(s_, q) && !isnan(c->arm_known[s_][q])) {
                 const double cst = fixed(s_, q) + LIST_COST * c->arm_known[s_][q];
                 if (cst < bc) { bc = cst; bs = s_; bp = q; }
@@ -486,7 +518,7 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
     int es = -1, ep = -1;
     double ec = bc;
     auto consider = [&](int s_, int q) {
-        if (s_ < 0 || s_ > 2 || q < 1 || q > 3 || !allowed(s_, q) || !isnan(c->arm_known[s_][q])) return;
+        if (s_ < 0 || s_ > 2 || q < 0 || q > 3 || !allowed(s_, q) || !isnan(c->arm_known[s_][q])) return;
         const double opt = fixed(s_, q);
         if (opt < ec) { ec = opt; es = s_; ep = q; }
     };
@@ -497,8 +529,17 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
         if (es < 0) consider(bs == 2 ? 2 : 1, 3);
     }
     if (es < 0) {
+        consider(bs, 0);  // (never run blind: see below)
         consider(bs, bp + 1); consider(bs, bp - 1);
         if (bs != 2) consider(1 - bs, bp);
+    }
+    // arm 0 is looked at by a counting-only launch beside an arm whose lists are known to be
+    // bearable (isotropic data: the whole map survives the triangle inequality -- an exact stage
+    // over such lists would cost ten ordinary epochs)
+    if (es >= 0 && ep == 0) {
+        c->probe_next = true;
+        ep = bp ? bp : 1;
+        if (!isnan(c->arm_known[es][ep])) { es = bs; ep = bp ? bp : 1; }
     }
     if (remeasured)  // a second look at this arm: did it pay?
         c->arm_wait[row][p] = (bs == row && bp == p) ? 16 : (c->arm_wait[row][p] >= 64 ? 128 : 2 * c->arm_wait[row][p]);
@@ -513,11 +554,12 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M) {
 }
 
 // after an epoch has completed: look at how long the candidate lists were, decide what comes next
-void update_policy(dbgsom_ctx *c, double list_sum, int64_t nb, int64_t M) {
+void update_policy(dbgsom_ctx *c, double list_sum, double probe_sum, int64_t nb, int64_t M) {
     if (!c->last_filtered) { c->last_mean = NAN; return; }
     const double mean = nb ? list_sum / (double)nb : 0.0;
     c->last_mean = mean;
-    adapt_arms(c, mean, M);
+    c->last_probe_mean = c->last_probed && nb ? probe_sum / (double)nb : NAN;
+    adapt_arms(c, mean, M, nb * 128);
     if (c->algorithm == DBGSOM_ALG_AUTO) {
         // (the cheapest arm known so far, not an arm that is only being looked at)
         if (c->best_mean > (double)c->max_mean_candidates) {  // exponential back-off, capped
@@ -609,7 +651,7 @@ int smooth_and_fetch(dbgsom_ctx *c, int64_t M, double sigma, int layout, int fla
     mark(c, 3);
     // the epoch's small results: one kernel writes them into mapped page-locked memory, one stream
     // synchronisation
-    TRY(c->tail.reserve((size_t)(2 * M + 3) * 8));
+    TRY(c->tail.reserve((size_t)(2 * M + 4) * 8));
     double *tail = c->tail.as<double>();
     const unsigned long long *list_sum =
         c->last_filtered ? dbgsom_filter_count_sum_ptr(c->filt_ws.p, s.N, dp, M) : nullptr;
@@ -683,7 +725,7 @@ int dbgsom_ctx_create(int device, dbgsom_ctx **out) {
     if (!c) { set_error("out of host memory"); return DBGSOM_ENOMEM; }
     c->device = device;
     const char *e = getenv("DBGSOM_SWEEP_PLANES");  // diagnostic: fixes the digit planes of every context
-    if (e) { const int v = atoi(e); if (v >= 0 && v <= 3) c->sweep_planes = v; }
+    if (e) { const int v = atoi(e); if (v >= 0 && v <= 4) c->sweep_planes = v; }
     hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (err != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(err));
@@ -718,7 +760,7 @@ int dbgsom_ctx_set_option(dbgsom_ctx *c, const char *name, int64_t v) {
         DBGSOM_REQUIRE(v >= DBGSOM_ALG_AUTO && v <= DBGSOM_ALG_FILTERED_HINT, "algorithm must be a DBGSOM_ALG_* value");
         c->algorithm = (int)v;
     } else if (!strcmp(name, "sweep_planes")) {
-        DBGSOM_REQUIRE(v >= 0 && v <= 3, "sweep_planes must be 0 .. 3");
+        DBGSOM_REQUIRE(v >= 0 && v <= 4, "sweep_planes must be 0 .. 4 (4 = no sweep: triangle pruning)");
         c->sweep_planes = (int)v;
     } else if (!strcmp(name, "seed_stride")) {
         DBGSOM_REQUIRE(v >= 0 && v <= 64, "seed_stride outside [0, 64]");
@@ -803,6 +845,7 @@ static void reset_training_state(dbgsom_ctx *c) {
     c->planeM = -1;
     c->plane_hold = 0;
     c->seed_mode = 0;
+    c->probe_next = c->last_probed = false;
     c->last_filtered = false;
     c->last_mean = NAN;
     c->sumsM = 0;
@@ -998,9 +1041,10 @@ int dbgsom_ctx_bmu_query(dbgsom_ctx *c, const void *Xq_host, int x_dtype, int64_
         if (filt) {
             if ((rc = ensure_planes(c, s))) break;
             if ((rc = fws.reserve_zeroed(dbgsom_bmu_filtered_workspace_bytes(Nq, dp, M), c->stream))) break;
-            const int planes = planes_for_call(c);
+            int stride = c->seed_stride, planes = 1;
+            filter_call_args(planes_for_call(c), false, M, &stride, &planes);
             rc = dbgsom_bmu_filtered(s.Xb, s.bdtype, Nq, dp, dp, s.xx.as<double>(), s.planes.p, Wq.as<double>(), M,
-                                     wwq.as<double>(), nullptr, nullptr, c->seed_stride, planes, round_f32,
+                                     wwq.as<double>(), nullptr, nullptr, stride, planes, round_f32,
                                      iq.as<int64_t>(), dq.as<double>(), fws.p, fws.cap, c->stream);
         } else {
             rc = launch_bmu(s.Xb, s.bdtype, Nq, dp, dp, s.xx.as<double>(), Wq.as<double>(), M, wwq.as<double>(), k,
@@ -1063,7 +1107,7 @@ int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f
                               idx, idx_host, dist_host);
         if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) break;
         c->last_frozen = (flags & DBGSOM_EPOCH_FROZEN) != 0;
-        update_policy(c, c->tail.as<double>()[2 * M + 2], (s.N + 127) / 128, M);
+        update_policy(c, c->tail.as<double>()[2 * M + 2], c->tail.as<double>()[2 * M + 3], (s.N + 127) / 128, M);
     } while (0);
     if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) { (void)hipStreamSynchronize(c->stream); c->hint_valid = false; }
     return rc;
@@ -1338,7 +1382,7 @@ int dbgsom_ctx_epoch_info(dbgsom_ctx *c, double *info8) {
     info8[3] = c->last_hinted ? 1.0 : 0.0;
     info8[4] = (double)c->filter_backoff;
     info8[5] = (double)c->plane_hold;
-    info8[6] = 0.0;
+    info8[6] = c->last_filtered && c->last_probed ? c->last_probe_mean : NAN;
     info8[7] = c->last_filtered && c->last_seed_full ? 1.0 : 0.0;
     return DBGSOM_OK;
 }

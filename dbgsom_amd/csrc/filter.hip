@@ -32,7 +32,7 @@ constexpr int FNT = 512;          // threads per sweep workgroup (8 wavefronts)
 constexpr int FSTAGES = 3;
 constexpr int PREPASS_KTILES = 3;  // k-tiles the seed pre-pass samples (tile_select_kernel picks them)
 constexpr int SCHED_BINS = 16;     // launch-order bins of the exact stage (section 2b)
-constexpr int SCHED_CTR = 2 * SCHED_BINS + 8;  // bin counts | cursors | [start, n] of classes 3, 2, 1 | sum of list lengths (u64)
+constexpr int SCHED_CTR = 2 * SCHED_BINS + 10;  // bin counts | cursors | [start, n] of classes 3, 2, 1 | sum of list lengths (u64) | the same of a counting-only pruning launch (u64)
 constexpr int SCHED_SUM = 2 * SCHED_BINS + 6;  // (8-byte aligned: the counters sit on a 256-byte boundary)
 constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
 #ifndef SUBSET_EXPERIMENT
@@ -46,7 +46,8 @@ constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
 #define SWEEP_EXPERIMENT 0  // 4 no MFMA, 8 no chunk epilogue,
 // 64 (with 8) products dead, 256 in-kernel s_memtime stamps (tools/sweep_stamps.py), 512 passing
 // pairs (tools/sweep_survivors.py), 1024 stamps in sweep4_i8_kernel (tools/sweep4_stamps.py),
-// 2048 sweep4_i8_kernel reads the fragments of every second k-step only (LDS share of its time)
+// 2048 sweep4_i8_kernel reads the fragments of every second k-step only (LDS share of its time),
+// 4096 sweep4_i8_kernel streams the same 1024 X rows in every workgroup (share of the X re-reads)
 #endif
 
 // plane rows are padded to whole k-tiles, at least two of them (the sweep's ring runs three tiles
@@ -268,8 +269,8 @@ __device__ __forceinline__ void slice_w_row(const double *__restrict__ W, int M,
                                             int stride, int Msubpad, int nkt_used,
                                             const int32_t *__restrict__ kt_sel, int8_t *__restrict__ wt,
                                             int8_t *__restrict__ wt_sub, double *__restrict__ scale,
-                                            double *__restrict__ l1, double *__restrict__ yy_part, int row,
-                                            int lane) {
+                                            double *__restrict__ l1, double *__restrict__ yy_part,
+                                            double *__restrict__ nrm0, int row, int lane) {
     const double *a = W + (size_t)row * d;
     double m = 0.0, s1 = 0.0;
     for (int k = lane; k < d; k += 64) {
@@ -295,6 +296,7 @@ __device__ __forceinline__ void slice_w_row(const double *__restrict__ W, int M,
         for (int off = 32; off > 0; off >>= 1) p2 += __shfl_xor(p2, off, 64);
         if (lane == 0) yy_part[q] = p2;
     }
+    long long n0 = 0;  // sum of the squared top digits (exact)
     for (int k = lane; k < dpad; k += 64) {
         int v = 0;
         if (k < d) v = (int)rint(a[k] / s * FQ);
@@ -302,6 +304,7 @@ __device__ __forceinline__ void slice_w_row(const double *__restrict__ W, int M,
         const int v1 = (v - d2) >> 8;
         const int d1 = ((v1 + 128) & 255) - 128;
         const int d0 = (v1 - d1) >> 8;
+        n0 += (long long)(d0 * d0);
         const int kt = k >> 6, c = (k >> 4) & 3, b = k & 15;
         const size_t o = ((size_t)kt * Mpad + row) * FKT + ((c ^ ((row >> 2) & 3)) << 4) + b;
         wt[o] = (int8_t)d0;
@@ -314,6 +317,8 @@ __device__ __forceinline__ void slice_w_row(const double *__restrict__ W, int M,
             wt_sub[2 * sub_stride + oq] = (int8_t)d2;
         }
     }
+    for (int off = 32; off > 0; off >>= 1) n0 += __shfl_xor(n0, off, 64);
+    if (lane == 0) nrm0[row] = (double)n0;
 }
 
 
@@ -326,11 +331,12 @@ __global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__rest
                                                             double *__restrict__ scale,
                                                             double *__restrict__ l1,
                                                             double *__restrict__ yy_part,
+                                                            double *__restrict__ nrm0,
                                                             uint32_t *__restrict__ ticket, WTables tables) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row < M) slice_w_row(W, M, d, dpad, Mpad, stride, Msubpad, nkt_used, kt_sel, wt, wt_sub, scale, l1, yy_part,
-                             row, lane);
+                             nrm0, row, lane);
     // the per-prototype tables of the sweep need every row's scale / l1 / partial norm: the
     // workgroup that finishes last builds them (one launch less than a kernel of their own)
     if (last_workgroup_done(ticket, gridDim.x)) wtables_body<256>(scale, l1, yy_part, M, Mpad, stride, tables);
@@ -1116,6 +1122,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
         const int r = 16 * (XI * wave + u) + (lane >> 2);
         const int64_t xpos = (p0 + r < N) ? (p0 + r) : (N - 1);
         i_dr[u] = sample_at(xpos);
+#if SWEEP_EXPERIMENT & 4096
+        i_dr[u] &= 1023;  // timing experiment: every workgroup's X rows come from the same 1024 (L2 hits; results are wrong)
+#endif
         dc[u] = (lane & 3) ^ ((r >> 2) & 3);
     }
     int64_t i_il[2];
@@ -1620,6 +1629,266 @@ __global__ __launch_bounds__(256) void sched_fill_kernel(const uint32_t *__restr
     if (bin >= 0) sched[base[bin] + r] = b;
 }
 
+// ---- 2c. candidates without a sweep: the triangle inequality --------------------------------------
+// Clustered data (what a trained map sits on) lets most of the map be ruled out before any product
+// with the sample is formed: with p = the sample's seed,
+//     |x_i - w_j| >= |w_p - w_j| - |x_i - w_p|   (real arithmetic, Euclidean norms),
+// so a prototype j with |w_p - w_j| >= 2 |x_i - w_p| + m is at least m further from x_i than the seed.
+// Two certified ingredients, both from the TOP digit plane alone.  With a^ = s D0 / 127 the row that
+// plane stands for, |a_k - a^_k| <= (s / F)(2^15 + 2^7 + 1/2 + 3 u F) <= s / 253, so |a - a^| <= e_a :=
+// sqrt(d) s / 253 (Euclidean), and distances between such rows are exact integer sums:
+// |x^ - w^|^2 = (s^2 A - 2 s t P + t^2 B) / 127^2, A = sum D0x^2, B = sum D0w^2, P = sum D0x D0w.
+//   gap[p][j]  <= |w_p - w_j|^2     float32: (|w^_p - w^_j| - e_p - e_j)^2, rounded down (proto_gap_kernel);
+//   bound_i    >= (2 |x_i - w_p| + m_i)^2  with |x_i - w_p| <= |x^_i - w^_p| + e_i + e_p
+//                 (prune_mark_kernel: one pass over the top plane of X), and
+//                 m_i = sqrt(2 rho_i), rho_i = 4 (d + 16) 2^-53 (|x_i|^2 + max |w|^2) -- at least twice
+//                 what the exact kernel's chain can be off the real squared distance by.
+// (The bound filter_eps gives for r~ is of no use here: its worst case over the dropped digit
+//  products, ~ 0.008 d s t for one plane, exceeds the squared distances between the clusters.)
+// gap[p][j] >= bound_i  =>  |x_i - w_j|^2 >= |x_i - w_p|^2 + m_i^2  =>  r_chain(i, j) > r_chain(i, p):
+// j can neither win nor tie.  The candidates of a 128-sample workgroup are the prototypes that
+// survive for any of its samples; samples arrive in bucket order of their seeds, so a workgroup has
+// a few distinct seeds (runs) and tests a few rows of the gap matrix against the runs' largest bounds.
+// Same outputs as the sweep (ulist / ucount / schedule counters): the exact stage does not know
+// which of the two produced its lists.  What it costs: one pass over the X plane and an M x M matrix
+// per epoch instead of N x M digit products; what it yields depends on the data alone (blobs: the
+// sample's own cluster; isotropic data: the whole map -- the engine's policy measures it with a
+// counting-only launch before it lets the exact stage loose on such lists).
+constexpr int PRUNE_MAX_M = 8192;  // the gap matrix: 4 M^2 bytes (256 MB here)
+
+// relative size of what the lower digits and the rounding of the quantisation add to a feature:
+// (2^15 + 2^7 + 1/2 + 3 u F) / F
+constexpr double PLANE0_ERR = 32897.0 / (127.0 * 65536.0) * (1.0 + 1e-6);
+
+// gap[j ldg + p] for a 64 x 64 tile of (p, j); one wavefront per tile, operands straight from the
+// k-tile-major top plane (L2-resident), P = D0 . D0
+__global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict__ wt, int w_rows, int dpad, int M, int d,
+                                                       const double *__restrict__ tw, const double *__restrict__ wn0,
+                                                       float *__restrict__ gap, int ldg) {
+    const int lane = threadIdx.x, lc = lane & 31, lh = lane >> 5;
+    const int pb = blockIdx.x * 64, jb = blockIdx.y * 64;
+    const int nks = dpad / 32;  // dpad is a multiple of 64
+    const int8_t *base[2][2];   // [side: 0 = p, 1 = j][32-row block]: this lane's row
+    int sw[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int rp = pb + b * 32 + lc, rj = jb + b * 32 + lc;
+        base[0][b] = wt + (size_t)rp * FKT; sw[0][b] = (rp >> 2) & 3;
+        base[1][b] = wt + (size_t)rj * FKT; sw[1][b] = (rj >> 2) & 3;
+    }
+    struct Fr { v4i_t v[2][2]; };  // [side][block]
+    auto load = [&](int ks, Fr &f) {
+        const size_t tile = (size_t)(ks >> 1) * w_rows * FKT;
+        const int c = (ks & 1) * 2 + lh;
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                f.v[sd][b] = *reinterpret_cast<const v4i_t *>(base[sd][b] + tile + ((c ^ sw[sd][b]) << 4));
+    };
+    v16i_t P[2][2];  // [jt][it]
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[jt][it][r] = 0;
+    Fr f0, f1, f2, f3;
+    load(0, f0);
+    load(1, f1);
+    for (int ks = 0; ks < nks; ks += 4) {  // two k-steps in flight behind the two being multiplied
+        if (ks + 2 < nks) { load(ks + 2, f2); load(ks + 3, f3); }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                P[jt][it] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0.v[1][jt], f0.v[0][it], P[jt][it], 0, 0, 0);
+                P[jt][it] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f1.v[1][jt], f1.v[0][it], P[jt][it], 0, 0, 0);
+            }
+        if (ks + 2 >= nks) break;
+        if (ks + 4 < nks) { load(ks + 4, f0); load(ks + 5, f1); }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                P[jt][it] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f2.v[1][jt], f2.v[0][it], P[jt][it], 0, 0, 0);
+                P[jt][it] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f3.v[1][jt], f3.v[0][it], P[jt][it], 0, 0, 0);
+            }
+    }
+    const double root_d = sqrt((double)d) * (1.0 + 1e-12);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int p = pb + it * 32 + lc;
+        const bool pok = p < M;
+        const double tp = pok ? tw[p] : 0.0, Bp = pok ? wn0[p] : 0.0;
+        const double ep = root_d * tp * PLANE0_ERR;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jb + jt * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+                if (!pok || j >= M) continue;
+                const double tj = tw[j], Bj = wn0[j], Pv = (double)P[jt][it][r];
+                const double sq = tp * tp * Bp + tj * tj * Bj, cr = 2.0 * tp * tj * Pv;
+                const double dh2 = ((sq - cr) - 1e-12 * (sq + fabs(cr))) / 16129.0;
+                const double lo = (dh2 > 0.0 ? sqrt(dh2) * (1.0 - 1e-12) : 0.0) - (ep + root_d * tj * PLANE0_ERR);
+                const double v = lo > 0.0 ? lo * lo * (1.0 - 1e-6) : 0.0;
+                // (anything that is not a positive finite number: no gap known)
+                gap[(size_t)j * ldg + p] = (v > 0.0 && v < 3.0e38) ? __double2float_rz(v) : 0.f;
+            }
+    }
+}
+
+// the candidate lists of the 128-sample workgroups by the rule above.  count_only: only the sum of
+// the list lengths (into sum_out) -- what the lists WOULD be, for the engine's policy.
+__global__ __launch_bounds__(256) void prune_mark_kernel(
+    const int8_t *__restrict__ xplanes, const double *__restrict__ sx, const double *__restrict__ xx, int64_t N, int d,
+    int dpad, const int8_t *__restrict__ wplanes, int w_rows, const double *__restrict__ tw,
+    const double *__restrict__ summary, int M,
+    const int64_t *__restrict__ prev, const int32_t *__restrict__ order, const float *__restrict__ gap, int ldg,
+    uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, uint32_t *__restrict__ sched_ctr,
+    unsigned long long *__restrict__ sum_out, int count_only) {
+    __shared__ int prev_s[128], run_p[128];
+    __shared__ int64_t samp_s[128];
+    __shared__ unsigned long long bound_s[128], run_t[128];  // non-negative doubles by their bit patterns
+    __shared__ uint32_t mask[PRUNE_MAX_M / 32];
+    __shared__ int misc[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t p0 = (int64_t)blockIdx.x * 128;
+    const int nwords = (M + 31) / 32;
+    const unsigned long long INF_BITS = 0x7ff0000000000000ull;
+    for (int w = tid; w < nwords; w += 256) mask[w] = 0u;
+    if (tid < 128) {
+        const int64_t p = p0 + tid;
+        int pj = -2;  // no sample
+        int64_t i = 0;
+        if (p < N) {
+            i = (int64_t)order[p];
+            const int64_t q = prev[i];
+            pj = (q >= 0 && q < M) ? (int)q : -1;  // -1: a sample without a usable seed
+        }
+        prev_s[tid] = pj;
+        samp_s[tid] = i;
+        run_t[tid] = 0ull;
+    }
+    if (tid == 0) misc[0] = 0;  // 1: some sample has no bound -- every prototype is a candidate
+    __syncthreads();
+    // |x_i - w_seed|^2 from one digit product: 8 threads per sample, 16 bytes of the row each per step
+    const double yy_max = summary[2], root_d = sqrt((double)d) * (1.0 + 1e-12);
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        const int il = round * 32 + (tid >> 3), q = tid & 7;
+        const int pj = prev_s[il];
+        const int64_t i = samp_s[il];
+        int a0 = 0, ax = 0, aw = 0;  // P, A, B of the header
+        if (pj >= 0) {
+            const int8_t *xr = xplanes + (size_t)i * dpad;
+            const int wsw = (pj >> 2) & 3;
+            for (int ch = q; ch < dpad / 16; ch += 8) {
+                const int8_t *wr = wplanes + ((size_t)(ch >> 2) * w_rows + pj) * FKT + (((ch & 3) ^ wsw) << 4);
+                const v4i_t x0 = *reinterpret_cast<const v4i_t *>(xr + ch * 16);
+                const v4i_t w0 = *reinterpret_cast<const v4i_t *>(wr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a0 = __builtin_amdgcn_sdot4(x0[e], w0[e], a0, false);
+                    ax = __builtin_amdgcn_sdot4(x0[e], x0[e], ax, false);
+                    aw = __builtin_amdgcn_sdot4(w0[e], w0[e], aw, false);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+            a0 += __shfl_xor(a0, m, 64); ax += __shfl_xor(ax, m, 64); aw += __shfl_xor(aw, m, 64);
+        }
+        if (q == 0 && pj != -2) {
+            unsigned long long bits = INF_BITS;
+            if (pj >= 0) {
+                const double sv = sx[i], tv = tw[pj];
+                const double sq = sv * sv * (double)ax + tv * tv * (double)aw, cr = 2.0 * sv * tv * (double)a0;
+                const double dh2 = ((sq - cr) + 1e-12 * (sq + fabs(cr))) / 16129.0;
+                const double rho = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xx[i] + yy_max);
+                const double up = (dh2 > 0.0 ? sqrt(dh2) * (1.0 + 1e-12) : 0.0) + root_d * (sv + tv) * PLANE0_ERR;
+                if (fabs(up) < INFINITY) {  // (a NaN fails this too)
+                    const double b = 2.0 * up * (1.0 + 1e-12) + (sqrt(2.0 * rho) * 1.0001 + 1e-300);
+                    const double b2 = b * b * (1.0 + 1e-12);
+                    if (b2 < INFINITY) bits = (unsigned long long)__double_as_longlong(b2);
+                }
+            }
+            bound_s[il] = bits;
+            if (bits == INF_BITS) misc[0] = 1;
+        }
+    }
+    __syncthreads();
+    const bool all = misc[0] != 0;
+    if (!all) {
+        // runs of equal seeds (the samples come sorted by seed; any other order only makes more runs)
+        if (wave == 0) {
+            const int pa = prev_s[lane], pb_ = prev_s[lane + 64];
+            const bool ha = pa != -2 && (lane == 0 || prev_s[lane - 1] != pa);
+            const bool hb = pb_ != -2 && prev_s[lane + 63] != pb_;
+            const uint64_t ba = __builtin_amdgcn_ballot_w64(ha), bb = __builtin_amdgcn_ballot_w64(hb);
+            const uint64_t below = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);  // positions <= lane
+            const int ra = __popcll(ba & below) - 1, rb = __popcll(ba) + __popcll(bb & below) - 1;
+            if (ha) run_p[ra] = pa;
+            if (hb) run_p[rb] = pb_;
+            if (pa != -2) atomicMax(&run_t[ra], bound_s[lane]);
+            if (pb_ != -2) atomicMax(&run_t[rb], bound_s[lane + 64]);
+            if (lane == 0) misc[1] = __popcll(ba) + __popcll(bb);
+        }
+        __syncthreads();
+        const int nrun = misc[1];
+        for (int r = 0; r < nrun; ++r) {
+            const int p = run_p[r];
+            const double T = __longlong_as_double((long long)run_t[r]);
+            const float *row = gap + (size_t)p * ldg;
+            for (int j0 = wave * 64; j0 < M; j0 += 256) {  // a wave owns its mask words
+                const int j = j0 + lane;
+                const bool keep = j < M && (j == p || !((double)row[j] >= T));
+                const uint64_t b = __builtin_amdgcn_ballot_w64(keep);
+                if (lane == 0) {
+                    mask[j0 >> 5] |= (uint32_t)b;
+                    if ((j0 >> 5) + 1 < nwords) mask[(j0 >> 5) + 1] |= (uint32_t)(b >> 32);
+                }
+            }
+        }
+    } else {
+        for (int w = tid; w < nwords; w += 256) {
+            const int left = M - w * 32;
+            mask[w] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {  // compact the marked prototypes, ascending (as the sweeps do)
+        uint32_t base = 0;
+        uint16_t *out = ulist + (size_t)blockIdx.x * ulist_stride;
+        for (int w0 = 0; w0 < nwords; w0 += 64) {
+            const int w = w0 + lane;
+            uint32_t bits = (w < nwords) ? mask[w] : 0u;
+            const uint32_t cnt = __popc(bits);
+            uint32_t pre = cnt;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(pre, off, 64);
+                if (lane >= off) pre += v;
+            }
+            uint32_t pos = base + pre - cnt;
+            if (!count_only)
+                while (bits) {
+                    const int b = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    out[pos++] = (uint16_t)(w * 32 + b);
+                }
+            base += __shfl(pre, 63, 64);
+        }
+        if (lane == 0) {
+            if (!count_only) {
+                ucount[blockIdx.x] = base;
+                atomicAdd(&sched_ctr[sched_bin(base)], 1u);
+            }
+            atomicAdd(sum_out, (unsigned long long)base);
+        }
+    }
+}
+
 // ---- 3. exact arg-min over the marked prototypes (float64 MFMA on gathered rows) -----------------
 // 128 gathered samples x SJ = 16 JTL listed prototypes per step; 4 wavefronts x 32 samples or 8 x 16
 // (NWV), 3-stage LDS-DMA ring.  Three instantiations (JTL = 1, 2, 3) are launched back to back, each
@@ -1922,6 +2191,7 @@ struct FilterWs {
                            // the workspace whatever its shape; 0 between launches, see last_workgroup_done)
     int8_t *wt, *wt_sub;   // k-tile-major digit planes of the prototypes / of the pre-pass subset
     double *wscale, *wl1;  // M each
+    double *wn0;           // M: sum of the squared top digits of a row (section 2c)
     double *ctab, *yypad, *ctab_sub, *yy_sub, *ictab, *yctab, *yy_part, *summary;
     float *tab32;        // 4 x Mpad float32: [yctab | ictab | yy_sub | ctab_sub 2^16] for the 2-per-CU sweep's epilogue
     float *chk32;        // Mpad / 256 x 4 float32: [min yctab, min ictab, max ictab, -] per 256-prototype chunk
@@ -1934,6 +2204,8 @@ struct FilterWs {
     uint32_t *sched_ctr;  // SCHED_CTR counters of that schedule
     int64_t *seed;     // N   arg-min of the coarse pre-pass (when the caller has no previous winners)
     int32_t *order;    // N   bucket order of the samples by seed
+    float *gap;        // Mg x Mg lower bounds of the squared distances between prototypes (2c); M <= PRUNE_MAX_M
+    int64_t Mg;        // its leading dimension: M rounded up to 64
     void *sort_ws;
     int64_t nb, Mpad;
 };
@@ -1943,7 +2215,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t otk = take(256);
     const size_t ow = take((size_t)3 * Mpad * dpad), ows = take((size_t)3 * Mpad * dpad);
-    const size_t osc = take((size_t)M * 8), ol1 = take((size_t)M * 8);
+    const size_t osc = take((size_t)M * 8), ol1 = take((size_t)M * 8), on0 = take((size_t)M * 8);
     const size_t o0 = take((size_t)Mpad * 8), o1 = take((size_t)Mpad * 8), o2 = take(64);
     const size_t o8 = take((size_t)Mpad * 8), o9 = take((size_t)Mpad * 8);
     const size_t o10 = take((size_t)Mpad * 8), o11 = take((size_t)Mpad * 8), o12 = take((size_t)Mpad * 8);
@@ -1954,11 +2226,14 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
     const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
     const size_t o16 = take((size_t)nb * 4), o17 = take((size_t)SCHED_CTR * 4);
+    const int64_t Mg = (M + 63) / 64 * 64;
+    const size_t o20 = take(M <= PRUNE_MAX_M ? (size_t)Mg * Mg * 4 : 0);
     if (f) {
+        f->gap = M <= PRUNE_MAX_M ? (float *)(base + o20) : nullptr; f->Mg = Mg;
         f->tickets = (uint32_t *)(base + otk);
         f->sched = (int32_t *)(base + o16); f->sched_ctr = (uint32_t *)(base + o17);
         f->wt = (int8_t *)(base + ow); f->wt_sub = (int8_t *)(base + ows);
-        f->wscale = (double *)(base + osc); f->wl1 = (double *)(base + ol1);
+        f->wscale = (double *)(base + osc); f->wl1 = (double *)(base + ol1); f->wn0 = (double *)(base + on0);
         f->ctab = (double *)(base + o0); f->yypad = (double *)(base + o1);
         f->ctab_sub = (double *)(base + o8); f->yy_sub = (double *)(base + o9);
         f->ictab = (double *)(base + o10); f->yctab = (double *)(base + o11);
@@ -2109,6 +2384,11 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     // DBGSOM_SEED_FULL: the seed pre-pass looks at EVERY prototype and every feature (as expensive
     // as the sweep it seeds; what weakly clustered data needs -- the engine's policy decides)
     const bool seed_full = (seed_stride & DBGSOM_SEED_FULL) != 0;
+    // DBGSOM_PRUNE: candidates from the triangle inequality instead of the sweep (section 2c);
+    // DBGSOM_PRUNE_PROBE: the sweep as usual, and beside it what DBGSOM_PRUNE's lists would add up to
+    const bool prune = (seed_stride & DBGSOM_PRUNE) != 0 && M <= PRUNE_MAX_M;
+    const bool prune_probe = !prune && (seed_stride & DBGSOM_PRUNE_PROBE) != 0 && M <= PRUNE_MAX_M;
+    seed_stride &= ~(DBGSOM_PRUNE | DBGSOM_PRUNE_PROBE);
     seed_stride = seed_full ? 1 : seed_stride;
     DBGSOM_REQUIRE(seed_stride >= 0 && seed_stride <= 64, "seed_stride outside [0, 64]");
     DBGSOM_REQUIRE(sweep_planes >= 0 && sweep_planes <= 3, "sweep_planes must be 0 .. 3");
@@ -2165,7 +2445,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     hipLaunchKernelGGL(slice_w_tiled_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, W_dev,
                        (int)M, (int)d, dpad, (int)f.Mpad, seed_stride, Msubpad, nkt_used,
                        nkt_used < nkt_full ? f.kt_sel : (const int32_t *)nullptr, f.wt,
-                       f.wt_sub, f.wscale, f.wl1, f.yy_part, f.tickets + 1, tables);
+                       f.wt_sub, f.wscale, f.wl1, f.yy_part, f.wn0, f.tickets + 1, tables);
     g_timer.mark(1, s);
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
@@ -2206,9 +2486,21 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                        xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.yctab, f.ictab, f.yypad,    \
                        f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad,     \
                        f.ucount, (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr, f.sched_ctr)
+    if (prune || prune_probe) {
+        const unsigned gt = (unsigned)(f.Mg / 64);
+        hipLaunchKernelGGL(proto_gap_kernel, dim3(gt, gt), dim3(64), 0, s, f.wt, (int)f.Mpad, dpad, (int)M, (int)d,
+                           f.wscale, f.wn0, f.gap, (int)f.Mg);
+        unsigned long long *sum = reinterpret_cast<unsigned long long *>(f.sched_ctr + SCHED_SUM) + (prune ? 0 : 1);
+        hipLaunchKernelGGL(prune_mark_kernel, dim3((unsigned)f.nb), dim3(256), 0, s, xb.planes, xb.scale, xx_dev,
+                           N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, f.summary, (int)M, prev_idx_dev,
+                           order_dev, f.gap, (int)f.Mg, f.ulist, (int)f.Mpad, f.ucount, f.sched_ctr, sum,
+                           prune ? 0 : 1);
+    }
     // one digit product: 4-wavefront workgroups unless DBGSOM_SWEEP_SHAPE=8 (see dbgsom_sweep_shape)
     const int sweep_shape = dbgsom_sweep_shape(M, d);
-    if (sweep_planes == 1 && sweep_shape == 4 && order_dev && M <= Sweep4Lds::MAX_M) {
+    if (prune) {
+        // (no sweep)
+    } else if (sweep_planes == 1 && sweep_shape == 4 && order_dev && M <= Sweep4Lds::MAX_M) {
         // one digit product, 4-wavefront workgroups (128 x 256 tile), two of them per CU
         S4_LAUNCH(0, f.nb, xb.planes, xb.scale,
                            xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.tab32, f.tab32 + (size_t)f.Mpad, f.yypad, f.ctab,

@@ -52,6 +52,14 @@ extern "C" {
  * prototype and every feature (as expensive as the candidate sweep it seeds; pays on weakly
  * clustered data, where cheap seeds leave nearly every prototype a candidate) */
 #define DBGSOM_SEED_FULL 0x100
+/* OR-ed into `seed_stride` as well.  DBGSOM_PRUNE: no candidate sweep -- the candidates of a sample are
+ * the prototypes the triangle inequality cannot rule out from the distance to its seed and a certified
+ * lower bound of the distances between prototypes (filter.hip section 2c; M <= 8192, otherwise ignored).
+ * Same results, by construction; pays on clustered data, where it leaves the sample's own cluster.
+ * DBGSOM_PRUNE_PROBE: the sweep as usual, plus a counting-only run of that rule whose list-length sum
+ * dbgsom_ctx_epoch_info / the engine's policy reads (what DBGSOM_PRUNE would cost, without paying it). */
+#define DBGSOM_PRUNE 0x200
+#define DBGSOM_PRUNE_PROBE 0x400
 
 /* prototype-count limit of the accumulate step (per-block LDS histogram) */
 #define DBGSOM_MAX_PROTOTYPES 16000
@@ -227,7 +235,8 @@ int dbgsom_ctx_create(int device, dbgsom_ctx **out);
 int dbgsom_ctx_destroy(dbgsom_ctx *ctx);
 
 /* Integer options by name.  Settable: "algorithm" (DBGSOM_ALG_*), "sweep_planes" (0 adaptive,
- * 1..3 fixed digit planes of the candidate sweep), "seed_stride" (0 = library default),
+ * 1..3 fixed digit planes of the candidate sweep, 4 = no sweep: candidates from the triangle
+ * inequality, DBGSOM_PRUNE), "seed_stride" (0 = library default),
  * "timing" (1: HIP events around the phases of an epoch and the stages of the filter),
  * "filter_min_query_rows", "max_mean_candidates", "graph" (1: replay frozen / resident epochs from
  * a HIP graph).  Readable besides those: "n_samples", "features", "padded_features", "prototypes",
@@ -350,9 +359,10 @@ int dbgsom_ctx_partition(dbgsom_ctx *ctx, const double *W_host, int64_t M, int r
 int dbgsom_ctx_subset_create(dbgsom_ctx *ctx, int64_t neuron, dbgsom_ctx **child);
 
 /* ---- diagnostics ----------------------------------------------------------------------------- */
-/* info8 = [filtered search ran (0/1), mean candidate-list length, digit planes used, seeds were
- *          previous winners (0/1), back-off epochs left, plane-policy hold, launches replayed from
- *          a graph (0/1), stateless seeds came from the full pre-pass (0/1)] of the last epoch */
+/* info8 = [filtered search ran (0/1), mean candidate-list length, digit planes used (0 = no sweep:
+ *          triangle pruning), seeds were previous winners (0/1), back-off epochs left, plane-policy
+ *          hold, mean list length a counting-only pruning launch found beside the sweep (NaN: none
+ *          ran), stateless seeds came from the full pre-pass (0/1)] of the last epoch */
 int dbgsom_ctx_epoch_info(dbgsom_ctx *ctx, double *info8);
 /* candidate-list length per 128-sample workgroup of the last filtered search (n = ceil(N/128)) */
 int dbgsom_ctx_filter_counts(dbgsom_ctx *ctx, uint32_t *counts_host, int64_t n);

@@ -136,3 +136,88 @@ def test_coarse_prepass_is_a_valid_seed_source():
     # coarse seeds are near-minimal: within a few coarse error units of the true minimum
     gap = r[np.arange(200), seeds] - r.min(1)
     assert np.median(gap) < np.median(np.sort(r, 1)[:, 8] - r.min(1))
+
+
+# ---- candidates without a sweep: the triangle inequality (filter.hip section 2c) -------------------
+PLANE0_ERR = 32897.0 / (127.0 * 65536.0) * (1.0 + 1e-6)
+
+
+def prune_survivors(X, W, seeds):
+    """NumPy statement of proto_gap_kernel + prune_mark_kernel (top digit plane only): survivors[i, j]
+    is False only where the rule PROVES r(i, j) > r(i, seed_i)."""
+    d = X.shape[1]
+    (x0, _, _), sx, _ = slice_rows(X)
+    (w0, _, _), tw, _ = slice_rows(W)
+    root_d = np.sqrt(float(d)) * (1 + 1e-12)
+
+    def hat_dist2(a0, sa, b0, sb, sign):
+        """|a^ - b^|^2 of rows a^ = sa a0 / 127, nudged down (sign -1) or up (+1) by the rounding margin"""
+        A = (a0 * a0).sum(1).astype(np.float64)
+        B = (b0 * b0).sum(1).astype(np.float64)
+        P = (a0 @ b0.T).astype(np.float64)
+        sq = (sa * sa * A)[:, None] + (sb * sb * B)[None, :]
+        cr = 2.0 * sa[:, None] * sb[None, :] * P
+        return ((sq - cr) + sign * 1e-12 * (sq + np.abs(cr))) / 16129.0
+
+    dh2 = hat_dist2(w0, tw, w0, tw, -1)
+    lo = np.where(dh2 > 0, np.sqrt(np.maximum(dh2, 0)) * (1 - 1e-12), 0.0) \
+        - root_d * (tw[:, None] + tw[None, :]) * PLANE0_ERR
+    gap = np.where(lo > 0, lo * lo * (1 - 1e-6), 0.0)
+    g32 = gap.astype(np.float32)
+    g32 = np.where(g32.astype(np.float64) > gap, np.nextafter(g32, np.float32(0)), g32)   # rounded towards zero
+    gap = g32.astype(np.float64)
+    n = X.shape[0]
+    xx = (X ** 2).sum(1)
+    yy = (W ** 2).sum(1)
+    rho = 4.0 * (d + 16) * 1.1102230246251565e-16 * (xx + yy.max())
+    dxw = hat_dist2(x0, sx, w0, tw, +1)[np.arange(n), seeds]
+    up = np.where(dxw > 0, np.sqrt(np.maximum(dxw, 0)) * (1 + 1e-12), 0.0) + root_d * (sx + tw[seeds]) * PLANE0_ERR
+    b = 2.0 * up * (1 + 1e-12) + (np.sqrt(2.0 * rho) * 1.0001 + 1e-300)
+    bound = b * b * (1 + 1e-12)
+    keep = ~(gap[seeds] >= bound[:, None])
+    keep[np.arange(n), seeds] = True
+    return keep
+
+
+@pytest.mark.parametrize("name", [c[0] for c in CASES])
+def test_triangle_pruning_never_removes_a_possible_winner(name):
+    rng = np.random.default_rng(abs(hash("prune" + name)) % 2 ** 32)
+    X, W = dict((c[0], c[1]) for c in CASES)[name](rng)
+    X = np.asarray(X, dtype=np.float32).astype(np.float64)
+    W = np.asarray(W, dtype=np.float64)
+    W[1] = W[0]                                   # a duplicate and a near duplicate among the prototypes
+    W[2] = W[0] * (1 + 1e-13)
+    r = exact_r(X, W)
+    n = X.shape[0]
+    for seeds in (r.argmin(1), rng.integers(0, W.shape[0], n), np.zeros(n, int)):
+        keep = prune_survivors(X, W, seeds)
+        removed_can_win = ~keep & (r <= r[np.arange(n), seeds][:, None])
+        assert not removed_can_win.any(), name
+        assert keep[np.arange(n), r.argmin(1)].all()
+
+
+def test_triangle_pruning_leaves_the_own_cluster_on_blobs():
+    rng = np.random.default_rng(21)
+    d, k = 96, 12
+    centres = rng.normal(size=(k, d)) * 4
+    lab = rng.integers(0, k, 600)
+    X = (centres[lab] + rng.normal(size=(600, d))).astype(np.float32).astype(np.float64)
+    wl = rng.integers(0, k, 240)
+    W = centres[wl] + rng.normal(size=(240, d))
+    r = exact_r(X, W)
+    keep = prune_survivors(X, W, r.argmin(1))
+    same = lab[:, None] == wl[None, :]
+    assert not (keep & ~same).any()               # everything outside the sample's blob is ruled out
+    assert keep.sum(1).mean() < 1.5 * same.sum(1).mean()
+
+
+@pytest.mark.parametrize("name", [c[0] for c in CASES])
+def test_top_plane_stands_for_the_row_within_its_bound(name):
+    """|a_k - s D0_k / 127| <= s PLANE0_ERR: what the Euclidean error e_a = sqrt(d) s PLANE0_ERR rests on."""
+    rng = np.random.default_rng(abs(hash("res" + name)) % 2 ** 32)
+    X, W = dict((c[0], c[1]) for c in CASES)[name](rng)
+    for A in (np.asarray(X, dtype=np.float64), np.asarray(W, dtype=np.float64)):
+        (d0, _, _), s, _ = slice_rows(A)
+        res = np.abs(A - s[:, None] * d0 / 127.0)
+        assert (res <= s[:, None] * PLANE0_ERR).all()
+        assert np.sqrt((res ** 2).sum(1)).max() <= (np.sqrt(A.shape[1]) * s * PLANE0_ERR).max()

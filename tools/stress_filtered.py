@@ -40,7 +40,7 @@ for case in range(n_cases):
     ex = HipBackend(algorithm="exact").load(X, storage=storage)
     fi = HipBackend(algorithm="filtered_hint" if rng.random() < 0.5 else "filtered").load(X, storage=storage)
     fi.seed_stride = int(rng.choice([0, 1, 2, 8, 32]))
-    fi.sweep_planes = int(rng.choice([0, 1, 2, 3]))
+    fi.sweep_planes = int(rng.choice([0, 1, 2, 3, 4, 4]))
     print(f"case {case:3d} N={N} d={d} M={M} {kind} {dt} ...", flush=True)
     ok = True
     for e in range(2):
