@@ -212,6 +212,7 @@ class HipBackend(HotPathBackend):
     # cost model of the adaptive digit planes (mirrors engine.hip; tests recompute the choice)
     SWEEP_COST = {1: 0.35, 2: 1.0, 3: 1.96}
     LIST_COST = 12.5
+    PRUNE_PASS_COST = 60.0
 
     def __init__(self, device: Optional[int] = None, algorithm: str = "auto", _ctx=None):
         """algorithm (all give IDENTICAL results):
@@ -525,9 +526,16 @@ class HipBackend(HotPathBackend):
         self._log_epoch()
         return res
 
-    def _log_epoch(self):
+    def epoch_info(self):
+        """dbgsom_ctx_epoch_info of the last epoch: [filtered (0/1), mean candidate-list length,
+        digit planes (0 = no sweep), hinted (0/1), back-off epochs left, policy hold, mean list length
+        of a counting-only pruning launch (NaN: none), full seed pre-pass (0/1)]."""
         info = (ctypes.c_double * 8)()
         _native.call("dbgsom_ctx_epoch_info", self._ctx, info)
+        return [float(v) for v in info]
+
+    def _log_epoch(self):
+        info = self.epoch_info()
         if info[0]:
             self.filter_log.append(("filtered", float(info[1]), int(info[2])))
         elif self.algorithm != "exact":
@@ -583,6 +591,13 @@ class HipBackend(HotPathBackend):
         return {k: self._get(k) for k in keys}
 
     def plane_cost(self, p, mean, M):
+        """Cost model of the engine's policy (engine.hip) for `p` digit planes of the candidate
+        sweep and candidate lists of `mean` entries; p = 0: no sweep, candidates from the triangle
+        inequality (one pass over the top digit plane of X and an M x M matrix of prototype gaps)."""
+        if p == 0:
+            launches = 25.0 / (2.8 * max(self._N, 1) * self.padded_features / (1.0e6 * 784.0))
+            return (self.PRUNE_PASS_COST + self.SWEEP_COST[1] * M * 9.0 * M / max(self._N, 1) + launches
+                    + self.LIST_COST * mean)
         return self.SWEEP_COST[p] * M + self.LIST_COST * mean
 
     # -- f-1 .. f-3: reductions that keep the N-sized arrays in HBM -----------------------------

@@ -414,15 +414,17 @@ int stage_weights(dbgsom_ctx *c, const double *W_host, int64_t M, int64_t d, int
 
 // k = 1 search through the int8 filter; seeds = previous winners when `hinted`
 int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t M, int round_f32,
-                 const int64_t *prev_idx, const int32_t *order, int64_t *idx, double *dist) {
+                 const int64_t *prev_idx, const int32_t *order, int64_t *idx, double *dist, bool may_probe = false) {
     TRY(ensure_planes(c, s));
     TRY(ws.reserve_zeroed(dbgsom_bmu_filtered_workspace_bytes(s.N, s.dp, M), c->stream));
     c->planes_used = planes_for_call(c);
     if (c->planes_used == 0 && M > PRUNE_MAX_M) c->planes_used = 1;
     c->last_seed_full = !prev_idx && c->seed_mode == 1 && c->seed_stride == 0;
     int stride = c->last_seed_full ? DBGSOM_SEED_FULL : c->seed_stride, planes_arg = 1;
-    c->last_probed = c->probe_next && c->planes_used != 0 && M <= PRUNE_MAX_M;
-    c->probe_next = false;
+    // (a probe is read by the policy after a training epoch; the first epoch of a map size always has one)
+    c->last_probed = may_probe && c->sweep_planes == 0 && (c->probe_next || c->planeM != M) && c->planes_used != 0 &&
+                     M <= PRUNE_MAX_M;
+    if (may_probe) c->probe_next = false;
     filter_call_args(c->planes_used, c->last_probed, M, &stride, &planes_arg);
     TRY(dbgsom_bmu_filtered(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), s.planes.p, W, M,
                             c->ww.as<double>(), prev_idx, order, stride, planes_arg, round_f32, idx,
@@ -468,9 +470,10 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
     static const double SEED_COST[3] = {1.15, 2.0, 1.0};
     // (arm 0: the one-product pre-pass, one pass over the X plane and the gap matrix)
     auto fixed = [&](int s_, int q) {
-        if (q == 0)
+        if (q == 0)  // (+ two short dependent launches, ~25 us: what decides on small sample sets)
             return (SEED_COST[s_] - 1.0) * SWEEP_COST[1] * (double)M + PRUNE_PASS_COST +
-                   SWEEP_COST[1] * (double)M * 9.0 * (double)M / (double)(N > 0 ? N : 1);
+                   SWEEP_COST[1] * (double)M * 9.0 * (double)M / (double)(N > 0 ? N : 1) +
+                   25.0 / (2.8 * ((double)(N > 0 ? N : 1) * (double)c->xs.dp) / (1.0e6 * 784.0));
         return SEED_COST[s_] * SWEEP_COST[q] * (double)M;
     };
     // an arm's age = how often the map has been UPDATED since it ran (a frozen map -- the bench, a
@@ -519,7 +522,8 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
     double ec = bc;
     auto consider = [&](int s_, int q) {
         if (s_ < 0 || s_ > 2 || q < 0 || q > 3 || !allowed(s_, q) || !isnan(c->arm_known[s_][q])) return;
-        const double opt = fixed(s_, q);
+        // (no list is cheaper than one step of the exact stage: 16 entries)
+        const double opt = fixed(s_, q) + LIST_COST * fmin(16.0, (double)M);
         if (opt < ec) { ec = opt; es = s_; ep = q; }
     };
     const double best_mean = (bs == row && bp == p) ? mean : c->arm_known[bs][bp];
@@ -592,7 +596,7 @@ int epoch_bmu(dbgsom_ctx *c, int64_t M, int round_f32) {
         c->last_filtered = true;
         c->last_hinted = hint;
         TRY(run_filtered(c, s, c->filt_ws, W, M, round_f32, hint ? c->idx[c->icur].as<int64_t>() : nullptr,
-                         hint ? c->acc_ws.as<int32_t>() : nullptr, out, c->dist.as<double>()));
+                         hint ? c->acc_ws.as<int32_t>() : nullptr, out, c->dist.as<double>(), true));
     } else {
         c->last_filtered = false;
         if (c->filter_backoff > 0) --c->filter_backoff;

@@ -752,7 +752,7 @@ def test_filtered_search_randomised_shapes_dtypes_and_options():
         ex = HipBackend(algorithm="exact").load(X, storage=storage)
         fi = HipBackend(algorithm="filtered_hint" if rng.random() < 0.5 else "filtered").load(X, storage=storage)
         fi.seed_stride = int(rng.choice([0, 1, 2, 8, 32]))
-        fi.sweep_planes = int(rng.choice([0, 1, 2, 3]))   # 0 = adaptive
+        fi.sweep_planes = int(rng.choice([0, 1, 2, 3, 4]))   # 0 = adaptive, 4 = no sweep (triangle pruning)
         hop = np.abs(np.subtract.outer(np.arange(M), np.arange(M))).astype(np.float64)
         for e in range(2):
             re_ = ex.epoch(W, hop, 1.5, 1e-3, "aligned", True)
@@ -783,7 +783,7 @@ def test_filtered_search_with_extreme_row_scales(lo, hi):
     W[6] = X[3].astype(np.float64)
     hop = np.abs(np.subtract.outer(np.arange(M), np.arange(M))).astype(np.float64)
     ex = HipBackend(algorithm="exact").load(X)
-    for planes in (1, 2, 0):
+    for planes in (1, 2, 0, 4):
         fi = HipBackend(algorithm="filtered").load(X)
         fi.sweep_planes = planes
         for e in range(2):
@@ -814,7 +814,7 @@ def test_full_seed_prepass_on_weakly_clustered_data(o):
     fi = HipBackend(algorithm="filtered").load(X)
     ex = HipBackend(algorithm="exact").load(X)
     means, modes = [], []
-    for e in range(5):
+    for e in range(6):
         rf = fi.epoch(W, hop, 3.0, 1e-3, "compact", True)
         re_ = ex.epoch(W, hop, 3.0, 1e-3, "compact", True)
         assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances)
@@ -830,9 +830,11 @@ def test_full_seed_prepass_on_weakly_clustered_data(o):
 
 def test_adaptive_digit_planes_settle_on_the_cheaper_sweep(o):
     """sweep_planes = 0: the engine's arm policy (seeds x digit planes, cost model in engine.hip)
-    starts with cheap seeds and the one-product sweep; it stays there where the lists are short
-    (clustered data) and moves to a finer sweep where the coarse bound marks the whole map (a tiny
-    spread around a large mean).  Results are exact under every arm it tries."""
+    starts with cheap seeds and the one-product sweep.  On clustered data a counting-only launch
+    beside the first epoch's sweep shows that the triangle inequality leaves lists as short, and
+    the policy drops the sweep (arm 0); where the coarse bounds mark the whole map (a tiny spread
+    around a large mean: the same launch counts the whole map) it moves to a finer sweep.
+    Results are exact under every arm it tries."""
     from dbgsom_amd.backend import HipBackend
 
     rng = np.random.default_rng(3)
@@ -847,15 +849,22 @@ def test_adaptive_digit_planes_settle_on_the_cheaper_sweep(o):
         ex = HipBackend(algorithm="exact").load(X)
         assert int(be.sweep_planes) == 0
         q = ex.epoch(W, hop, 2.0, 1e-3, "compact", True)
+        probes = []
         for e in range(9):
             r = be.epoch(W, hop, 2.0, 1e-3, "compact", True)
             assert np.array_equal(r.winners, q.winners) and np.array_equal(r.distances, q.distances)
+            probes.append(be.epoch_info()[6])
         used = [entry[2] for entry in be.filter_log]
         means = [entry[1] for entry in be.filter_log]
         assert used[0] == 1 and used[-1] == used[-2] and be._get("plane_hold") > 0, used   # settled
-        if clustered:   # (either seed arm may win on a set this small; the coarse sweep does)
-            assert used[-1] == 1, (used, means)
+        assert not np.isnan(probes[0]), probes                           # looked at arm 0 beside epoch 1
+        if clustered:   # (on a set this small two more launches cost more than the sweep they replace:
+            #              the one-product sweep stays; the full-size test sees arm 0 win)
+            assert used[-1] in (0, 1) and means[-1] < 0.5 * M, (used, means, probes)
+            assert probes[0] < 0.5 * M, probes
         else:
+            assert probes[0] > 0.9 * M, probes                        # nothing to gain without a sweep
+            assert 0 not in used, used                                # ... so it never ran
             assert used[-1] >= 2 and means[-1] < 0.5 * means[0], (used, means)
         # what it settled on is the cheapest arm it has seen (cost model of the digit planes alone)
         seen = {p: m for (_, m, p) in be.filter_log[-3:]}
@@ -903,3 +912,47 @@ def test_one_product_sweep_at_the_edges_of_its_shapes(N, d, M):
         assert np.array_equal(rf.new_weights, re_.new_weights, equal_nan=True)
         fi.algorithm = "filtered_hint"
     ex.release(); fi.release()
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "bf16"])
+def test_candidates_from_the_triangle_inequality_alone(o, dt):
+    """sweep_planes = 4: no candidate sweep.  The candidates of a sample are what the triangle
+    inequality cannot rule out from a certified upper bound of its distance to the seed (one pass
+    over the top digit plane of X) and certified lower bounds of the distances between prototypes
+    (filter.hip section 2c).  Winners, distances and new prototypes are those of the all-pairs kernel and
+    of the oracle, bit for bit -- stateless and seeded by the previous winners, on blobs (where the
+    lists shrink to the sample's own cluster) and on data without clusters (where they cannot)."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(5)
+    N, d, rows, cols = 20_000, 200, 18, 20
+    M = rows * cols
+    hop = gi.lattice_hops(rows, cols)
+    Xb, _ = gi.blobs_f32(N, d, 31)
+    Xi = rng.normal(size=(N, d)).astype(np.float32)
+    for X, clustered in ((Xb, True), (Xi, False)):
+        X = X.astype(np.float64) if dt == "f64" else X
+        W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+        W[7] = W[3]                                   # duplicates: ties go to the lower index
+        ex = HipBackend(algorithm="exact").load(X, storage="bf16" if dt == "bf16" else None)
+        fi = HipBackend(algorithm="filtered").load(X, storage="bf16" if dt == "bf16" else None)
+        fi.sweep_planes = 4
+        for e in range(3):
+            re_ = ex.epoch(W, hop, 2.0, 1e-3, "compact", True)
+            rf = fi.epoch(W, hop, 2.0, 1e-3, "compact", True)
+            assert fi.filter_log[-1][0] == "filtered" and fi.filter_log[-1][2] == 0
+            assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances)
+            assert np.array_equal(rf.new_weights, re_.new_weights, equal_nan=True)
+            if clustered and e == 0:   # (prototypes drawn from the samples: about M / 32 per blob)
+                assert fi.filter_log[-1][1] < 0.35 * M, fi.filter_log[-1]
+            if e == 0:
+                Xr = X
+                if dt == "bf16":
+                    import torch
+                    Xr = torch.from_numpy(X).to(torch.bfloat16).float().numpy()
+                pick = rng.choice(N, 1500, replace=False)
+                rd, ri = o.bmu_chain(Xr[pick], W, 1)
+                assert np.array_equal(rf.winners[pick], ri) and np.array_equal(rf.distances[pick], rd)
+            fi.algorithm = "filtered_hint"
+            W = re_.new_weights
+        ex.release(); fi.release()
