@@ -126,6 +126,24 @@ __global__ void pack_results_kernel(const double *__restrict__ aE, int64_t M, co
     }
     __threadfence_system();
 }
+// shift[p] >= |a_p - b_p| (Euclidean, rows of two M x ld matrices) for p < rows, +inf beyond: how far a
+// prototype has moved since the distances of the hint were measured (filter.hip 2c); one wavefront per row
+__global__ __launch_bounds__(64) void row_shift_kernel(const double *__restrict__ A, const double *__restrict__ B,
+                                                       int64_t ld, int64_t d, int64_t rows, int64_t M,
+                                                       double *__restrict__ shift) {
+    const int64_t p = blockIdx.x;
+    if (p >= M) return;
+    if (p >= rows) { if (threadIdx.x == 0) shift[p] = INFINITY; return; }
+    double acc = 0.0;
+    if (A != B)
+        for (int64_t k = threadIdx.x; k < d; k += 64) {
+            const double t = A[p * ld + k] - B[p * ld + k];
+            acc = fma(t, t, acc);
+        }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    // (rounding of d squares and sums: relative d 2^-52 at most; NaN rows give NaN -- "no bound")
+    if (threadIdx.x == 0) shift[p] = sqrt(acc) * (1.0 + 1e-9);
+}
 __global__ void status_to_f64_kernel(const int32_t *__restrict__ status, double *__restrict__ out) {
     out[0] = status[0] ? 1.0 : 0.0;
 }
@@ -169,6 +187,7 @@ using namespace dbgsom;
 // the device-level ABI the engine drives (defined in filter.hip / stats.hip)
 extern "C" {
 const unsigned long long *dbgsom_filter_count_sum_ptr(const void *workspace_dev, int64_t N, int64_t d, int64_t M);
+void dbgsom_filter_hint_bound(const double *dist_prev_dev, const double *shift_dev);
 size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d);
 size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M);
 }
@@ -244,6 +263,12 @@ struct dbgsom_ctx {
     int filter_backoff = 0, filter_fail = 0;
     int planes_next = 1, planes_used = 1;   // 1 .. 3 digit planes of the sweep; 0 = no sweep (triangle pruning)
     bool probe_next = false, last_probed = false;  // a counting-only pruning launch beside the sweep
+    // `dist` holds the exact distances of the resident samples to the rows idx[icur] of Wb[distW_buf]
+    // (distW_M rows) as the last epoch's search left them: the hinted pruning bound (filter.hip 2c)
+    bool dist_bound_valid = false;
+    int distW_buf = 0;
+    int64_t distW_M = 0;
+    DevBuf shiftb;
     double last_probe_mean = NAN;
     int64_t planeM = -1;
     double arm_known[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};  // [seeds][planes]
@@ -401,6 +426,7 @@ int stage_weights(dbgsom_ctx *c, const double *W_host, int64_t M, int64_t d, int
     if (W_host) {
         TRY(c->Wb[c->cur].reserve((size_t)M * dp * 8));
         TRY(upload_padded(c, c->Wb[c->cur].p, W_host, M, d, dp, 8));
+        if (c->distW_buf == c->cur) c->dist_bound_valid = false;  // the matrix the hint's distances refer to is gone
         c->M = M;
         ++c->w_up_calls; c->w_up_bytes += M * d * 8;
     } else if (c->M != M) {
@@ -425,6 +451,17 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     c->last_probed = may_probe && c->sweep_planes == 0 && (c->probe_next || c->planeM != M) && c->planes_used != 0 &&
                      M <= PRUNE_MAX_M;
     if (may_probe) c->probe_next = false;
+    // seeds = the last epoch's winners, and their exact distances are still around: the pruning
+    // bound need not read X for samples whose prototype has hardly moved
+    if (may_probe && prev_idx && c->dist_bound_valid && dist == c->dist.as<double>() && M <= PRUNE_MAX_M &&
+        (c->planes_used == 0 || c->last_probed) && c->Wb[c->distW_buf].p) {
+        TRY(c->shiftb.reserve((size_t)M * 8));
+        const int64_t rows = c->distW_M < M ? c->distW_M : M;
+        hipLaunchKernelGGL(row_shift_kernel, dim3((unsigned)M), dim3(64), 0, c->stream, W,
+                           c->Wb[c->distW_buf].as<double>(), s.dp, s.dp, rows, M, c->shiftb.as<double>());
+        TRY(launch_status("row_shift_kernel"));
+        dbgsom_filter_hint_bound(c->dist.as<double>(), c->shiftb.as<double>());
+    }
     filter_call_args(c->planes_used, c->last_probed, M, &stride, &planes_arg);
     TRY(dbgsom_bmu_filtered(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), s.planes.p, W, M,
                             c->ww.as<double>(), prev_idx, order, stride, planes_arg, round_f32, idx,
@@ -606,6 +643,7 @@ int epoch_bmu(dbgsom_ctx *c, int64_t M, int round_f32) {
     c->icur ^= 1;
     c->hint_valid = false;  // re-established by the accumulate step that follows
     c->last_idx_valid = true;
+    c->dist_bound_valid = true; c->distW_buf = c->cur; c->distW_M = M;
     return DBGSOM_OK;
 }
 
@@ -850,6 +888,7 @@ static void reset_training_state(dbgsom_ctx *c) {
     c->plane_hold = 0;
     c->seed_mode = 0;
     c->probe_next = c->last_probed = false;
+    c->dist_bound_valid = false;
     c->last_filtered = false;
     c->last_mean = NAN;
     c->sumsM = 0;
@@ -954,6 +993,7 @@ int dbgsom_ctx_set_weights(dbgsom_ctx *c, const double *W_host, int64_t M) {
     DBGSOM_REQUIRE(W_host && M >= 1, "bad prototypes");
     TRY(c->Wb[c->cur].reserve((size_t)M * c->xs.dp * 8));
     TRY(upload_padded(c, c->Wb[c->cur].p, W_host, M, c->xs.d, c->xs.dp, 8));
+    if (c->distW_buf == c->cur) c->dist_bound_valid = false;
     c->M = M;
     ++c->w_up_calls; c->w_up_bytes += M * c->xs.d * 8;
     return sync(c);
@@ -1000,6 +1040,7 @@ int dbgsom_ctx_write_weight_rows(dbgsom_ctx *c, int64_t row0, int64_t n, const d
     TRY(c->Wb[c->cur].reserve_keep((size_t)newM * dp * 8, (size_t)c->M * dp * 8, c->stream));
     double *dst = c->Wb[c->cur].as<double>() + row0 * dp;
     TRY(upload_padded(c, dst, rows_host, n, d, dp, 8));
+    if (c->distW_buf == c->cur) c->dist_bound_valid = false;
     c->M = newM;
     c->w_row_writes += n;
     return sync(c);
@@ -1133,6 +1174,7 @@ int dbgsom_ctx_update(dbgsom_ctx *c, const double *W_host, int64_t M, const int6
         if ((rc = c->dist.reserve((size_t)s.N * 8))) break;
         if ((rc = c->kw.reserve((size_t)s.N * 8))) break;
         c->hint_valid = false;
+        c->dist_bound_valid = false;  // (the caller's distances: nothing a bound may rest on)
         c->icur ^= 1;
         int64_t *idx = c->idx[c->icur].as<int64_t>();
         hipError_t e = hipMemcpyAsync(idx, idx_host, (size_t)s.N * 8, hipMemcpyHostToDevice, c->stream);
@@ -1165,6 +1207,7 @@ int dbgsom_ctx_set_hint(dbgsom_ctx *c, const int64_t *idx_host, int64_t M) {
     TRY(launch_bucket_sort(idx, s.N, M, c->acc_ws.as<int32_t>(), c->part_ws.p, c->stream));
     TRY(sync(c));
     c->hint_valid = true;
+    c->dist_bound_valid = false;
     c->hintM = M;
     c->part_valid = false;
     return DBGSOM_OK;

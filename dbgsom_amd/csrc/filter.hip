@@ -1747,7 +1747,8 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
     const double *__restrict__ summary, int M,
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order, const float *__restrict__ gap, int ldg,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, uint32_t *__restrict__ sched_ctr,
-    unsigned long long *__restrict__ sum_out, int count_only) {
+    unsigned long long *__restrict__ sum_out, int count_only, const double *__restrict__ dist_prev,
+    const double *__restrict__ shift) {
     __shared__ int prev_s[128], run_p[128];
     __shared__ int64_t samp_s[128];
     __shared__ unsigned long long bound_s[128], run_t[128];  // non-negative doubles by their bit patterns
@@ -1775,27 +1776,64 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
     __syncthreads();
     // |x_i - w_seed|^2 from one digit product: 8 threads per sample, 16 bytes of the row each per step
     const double yy_max = summary[2], root_d = sqrt((double)d) * (1.0 + 1e-12);
+    // (the four samples of a thread side by side, two 16-byte steps each: 16 loads in flight -- one
+    //  sample and one step at a time the kernel waited for a load 28 times in a row)
+    const int q = tid & 7, nch = dpad / 16;
+    int a0r[4] = {0, 0, 0, 0}, axr[4] = {0, 0, 0, 0}, awr[4] = {0, 0, 0, 0};  // P, A, B of the header
+    const int8_t *xrow[4], *wrow[4];
+    int wswz[4];
+    bool live[4];
+    double hint_up[4];  // >= 0: the seed distance is known without the sample's row (see below)
 #pragma unroll
-    for (int round = 0; round < 4; ++round) {
-        const int il = round * 32 + (tid >> 3), q = tid & 7;
+    for (int r = 0; r < 4; ++r) {
+        const int il = r * 32 + (tid >> 3);
         const int pj = prev_s[il];
-        const int64_t i = samp_s[il];
-        int a0 = 0, ax = 0, aw = 0;  // P, A, B of the header
-        if (pj >= 0) {
-            const int8_t *xr = xplanes + (size_t)i * dpad;
-            const int wsw = (pj >> 2) & 3;
-            for (int ch = q; ch < dpad / 16; ch += 8) {
-                const int8_t *wr = wplanes + ((size_t)(ch >> 2) * w_rows + pj) * FKT + (((ch & 3) ^ wsw) << 4);
-                const v4i_t x0 = *reinterpret_cast<const v4i_t *>(xr + ch * 16);
-                const v4i_t w0 = *reinterpret_cast<const v4i_t *>(wr);
+        // Seeds that are the previous epoch's winners come with that epoch's exact distance to the
+        // OLD prototype; the new one has moved by shift[p] = |w'_p - w_p| at most (another triangle):
+        // |x_i - w'_p| <= dist_i (1 + 1e-7) + sqrt(rho_i) + shift_p  (the distance is the square root
+        // of a chain value within rho_i / 2 of the real one, possibly rounded to float32).  Taken when
+        // the prototype moved by less than a quarter of that distance -- a frozen or nearly settled
+        // map never reads X here; otherwise the row is read as for any other seed.
+        hint_up[r] = -1.0;
+        if (dist_prev && pj >= 0) {
+            const double dp = dist_prev[samp_s[il]], sh = shift[pj];
+            if (dp >= 0.0 && dp < INFINITY && sh >= 0.0 && sh <= 0.25 * dp) hint_up[r] = dp * (1.0 + 1e-7) + sh;
+        }
+        live[r] = pj >= 0 && !(hint_up[r] >= 0.0);
+        xrow[r] = xplanes + (size_t)samp_s[il] * dpad;
+        wrow[r] = wplanes + (size_t)(live[r] ? pj : 0) * FKT;
+        wswz[r] = live[r] ? (pj >> 2) & 3 : 0;
+    }
+    for (int ch0 = q; ch0 < nch; ch0 += 16) {
+        v4i_t xv[4][2], wv[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ch = ch0 + 8 * u;
+                const bool ok = live[r] && ch < nch;
+                const v4i_t zero = {0, 0, 0, 0};
+                xv[r][u] = ok ? *reinterpret_cast<const v4i_t *>(xrow[r] + ch * 16) : zero;
+                wv[r][u] = ok ? *reinterpret_cast<const v4i_t *>(wrow[r] + (size_t)(ch >> 2) * w_rows * FKT +
+                                                                 (((ch & 3) ^ wswz[r]) << 4)) : zero;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    a0 = __builtin_amdgcn_sdot4(x0[e], w0[e], a0, false);
-                    ax = __builtin_amdgcn_sdot4(x0[e], x0[e], ax, false);
-                    aw = __builtin_amdgcn_sdot4(w0[e], w0[e], aw, false);
+                    a0r[r] = __builtin_amdgcn_sdot4(xv[r][u][e], wv[r][u][e], a0r[r], false);
+                    axr[r] = __builtin_amdgcn_sdot4(xv[r][u][e], xv[r][u][e], axr[r], false);
+                    awr[r] = __builtin_amdgcn_sdot4(wv[r][u][e], wv[r][u][e], awr[r], false);
                 }
-            }
-        }
+    }
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        const int il = round * 32 + (tid >> 3);
+        const int pj = prev_s[il];
+        const int64_t i = samp_s[il];
+        int a0 = a0r[round], ax = axr[round], aw = awr[round];
 #pragma unroll
         for (int m = 1; m < 8; m <<= 1) {
             a0 += __shfl_xor(a0, m, 64); ax += __shfl_xor(ax, m, 64); aw += __shfl_xor(aw, m, 64);
@@ -1807,7 +1845,9 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
                 const double sq = sv * sv * (double)ax + tv * tv * (double)aw, cr = 2.0 * sv * tv * (double)a0;
                 const double dh2 = ((sq - cr) + 1e-12 * (sq + fabs(cr))) / 16129.0;
                 const double rho = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xx[i] + yy_max);
-                const double up = (dh2 > 0.0 ? sqrt(dh2) * (1.0 + 1e-12) : 0.0) + root_d * (sv + tv) * PLANE0_ERR;
+                const double up = hint_up[round] >= 0.0
+                                      ? hint_up[round] + sqrt(rho) * (1.0 + 1e-12)
+                                      : (dh2 > 0.0 ? sqrt(dh2) * (1.0 + 1e-12) : 0.0) + root_d * (sv + tv) * PLANE0_ERR;
                 if (fabs(up) < INFINITY) {  // (a NaN fails this too)
                     const double b = 2.0 * up * (1.0 + 1e-12) + (sqrt(2.0 * rho) * 1.0001 + 1e-300);
                     const double b2 = b * b * (1.0 + 1e-12);
@@ -1837,18 +1877,31 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
         }
         __syncthreads();
         const int nrun = misc[1];
-        for (int r = 0; r < nrun; ++r) {
-            const int p = run_p[r];
-            const double T = __longlong_as_double((long long)run_t[r]);
-            const float *row = gap + (size_t)p * ldg;
-            for (int j0 = wave * 64; j0 < M; j0 += 256) {  // a wave owns its mask words
-                const int j = j0 + lane;
-                const bool keep = j < M && (j == p || !((double)row[j] >= T));
-                const uint64_t b = __builtin_amdgcn_ballot_w64(keep);
-                if (lane == 0) {
-                    mask[j0 >> 5] |= (uint32_t)b;
-                    if ((j0 >> 5) + 1 < nwords) mask[(j0 >> 5) + 1] |= (uint32_t)(b >> 32);
+        // a wave owns its mask words: 64 prototypes at a time against every run, four rows of the gap
+        // matrix in flight (one at a time the workgroup waited for L2 once per run and step)
+#pragma unroll 2
+        for (int j0 = wave * 64; j0 < M; j0 += 256) {
+            const int j = j0 + lane;
+            const int jc = j < M ? j : M - 1;
+            bool keep = false;
+            for (int r = 0; r < nrun; r += 4) {
+                float g[4];
+                int pr[4];
+                double T[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = r + u < nrun ? r + u : r;
+                    pr[u] = run_p[rr];
+                    T[u] = __longlong_as_double((long long)run_t[rr]);
+                    g[u] = gap[(size_t)pr[u] * ldg + jc];
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) keep |= (j == pr[u]) || !((double)g[u] >= T[u]);
+            }
+            const uint64_t b = __builtin_amdgcn_ballot_w64(keep && j < M);
+            if (lane == 0) {
+                mask[j0 >> 5] = (uint32_t)b;
+                if ((j0 >> 5) + 1 < nwords) mask[(j0 >> 5) + 1] = (uint32_t)(b >> 32);
             }
         }
     } else {
@@ -2301,6 +2354,9 @@ struct SideStream {
     }
 };
 thread_local SideStream g_side;
+// (internal, engine.hip) distances / prototype shifts for the hinted form of the pruning bound: taken
+// by the NEXT dbgsom_bmu_filtered call of this thread that prunes, then forgotten
+thread_local const double *g_hint_dist = nullptr, *g_hint_shift = nullptr;
 }  // namespace
 
 extern "C" {
@@ -2309,6 +2365,10 @@ extern "C" {
  * dbgsom_bmu_filtered_stage_ms returns their durations for the LAST call, in milliseconds:
  * [0] slice W + tables, [1] coarse pre-pass (0 when a hint was given), [2] bucket sort,
  * [3] int8 sweep, [4] exact search on the candidates. */
+void dbgsom_filter_hint_bound(const double *dist_prev_dev, const double *shift_dev) {
+    g_hint_dist = dist_prev_dev; g_hint_shift = shift_dev;
+}
+
 int dbgsom_filter_timing(int enable) { g_timer.enabled = enable != 0; g_timer.valid = false; return DBGSOM_OK; }
 
 int dbgsom_bmu_filtered_stage_ms(double *ms5) {
@@ -2494,8 +2554,9 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         hipLaunchKernelGGL(prune_mark_kernel, dim3((unsigned)f.nb), dim3(256), 0, s, xb.planes, xb.scale, xx_dev,
                            N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, f.summary, (int)M, prev_idx_dev,
                            order_dev, f.gap, (int)f.Mg, f.ulist, (int)f.Mpad, f.ucount, f.sched_ctr, sum,
-                           prune ? 0 : 1);
+                           prune ? 0 : 1, g_hint_shift ? g_hint_dist : (const double *)nullptr, g_hint_shift);
     }
+    g_hint_dist = g_hint_shift = nullptr;
     // one digit product: 4-wavefront workgroups unless DBGSOM_SWEEP_SHAPE=8 (see dbgsom_sweep_shape)
     const int sweep_shape = dbgsom_sweep_shape(M, d);
     if (prune) {
