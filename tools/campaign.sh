@@ -4,8 +4,8 @@ O=$R/gpurun_out/camp
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for w in c4 c3 c2 c5; do
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/f_$w -- python3 $R/tools/run_frozen.py $w 4 filtered > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/w_$w -- python3 $R/tools/run_frozen.py $w 4 filtered > /dev/null 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/f_$w -- python3 $R/tools/run_frozen.py $w 5 filtered > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/w_$w -- python3 $R/tools/run_frozen.py $w 5 filtered > /dev/null 2>&1
   (cd $R && python tools/pmc_traffic.py $w $O/f_$w $O/w_$w > /dev/null)
   echo "pmc $w done"
 done
