@@ -15,7 +15,7 @@ tag = sys.argv[1]
 C = os.path.join(ROOT, "gpurun_out", "camp")
 P = os.path.join(ROOT, "profiles")
 for old in glob.glob(os.path.join(P, "r02_v[0-9]*_*")):
-    if "_v1_" not in old and f"_{tag}_" not in old:
+    if "_v1_" not in old and "_v4_" not in old and f"_{tag}_" not in old:   # v1: before the float32 epilogue; v4: last build whose default path swept
         os.remove(old)
 for w in ("c4", "c3", "c2", "c5"):
     shutil.copy(os.path.join(C, f"r02_{w}_pmc_traffic.txt"), P)
