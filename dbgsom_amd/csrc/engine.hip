@@ -112,7 +112,8 @@ __global__ void u64_to_f64_kernel(const unsigned long long *__restrict__ in, dou
 }
 // The epoch's small results in ONE kernel straight into page-locked host memory (no copy engine
 // round trips behind the last kernel: four queued D2H copies cost ~30 us per epoch):
-// out = [a (M) | E (M) | change_total | status | sum of candidate-list lengths | the same of a pruning probe]
+// out = [a (M) | E (M) | change_total | status | sum of candidate-list lengths | the same of a pruning probe |
+//        workgroups of the pruning form with long lists]
 __global__ void pack_results_kernel(const double *__restrict__ aE, int64_t M, const double *__restrict__ chg,
                                     const double *__restrict__ status, const unsigned long long *__restrict__ list_sum,
                                     double *__restrict__ out) {
@@ -123,6 +124,7 @@ __global__ void pack_results_kernel(const double *__restrict__ aE, int64_t M, co
         out[2 * M + 1] = status[0];
         out[2 * M + 2] = list_sum ? (double)list_sum[0] : 0.0;
         out[2 * M + 3] = list_sum ? (double)list_sum[1] : 0.0;  // (of a counting-only pruning launch)
+        out[2 * M + 4] = list_sum ? (double)list_sum[2] : 0.0;  // (workgroups whose pruned lists came out long)
     }
     __threadfence_system();
 }
@@ -263,6 +265,8 @@ struct dbgsom_ctx {
     int filter_backoff = 0, filter_fail = 0;
     int planes_next = 1, planes_used = 1;   // 1 .. 3 digit planes of the sweep; 0 = no sweep (triangle pruning)
     bool probe_next = false, last_probed = false;  // a counting-only pruning launch beside the sweep
+    bool last_retry = false;
+    bool prune_retry = false;  // the last pruning launch met workgroups with poor seeds: re-seed those (DBGSOM_PRUNE_RETRY)
     // `dist` holds the exact distances of the resident samples to the rows idx[icur] of Wb[distW_buf]
     // (distW_M rows) as the last epoch's search left them: the hinted pruning bound (filter.hip 2c)
     bool dist_bound_valid = false;
@@ -414,10 +418,10 @@ int planes_for_call(const dbgsom_ctx *c) {
     return c->sweep_planes ? (c->sweep_planes == 4 ? 0 : c->sweep_planes) : c->planes_next;
 }
 // the (seed_stride, sweep_planes) arguments of dbgsom_bmu_filtered for arm `planes`
-void filter_call_args(int planes, bool probe, int64_t M, int *stride, int *planes_arg) {
+void filter_call_args(int planes, bool probe, bool retry, int64_t M, int *stride, int *planes_arg) {
     *planes_arg = planes ? planes : 1;
-    if (!planes && M <= PRUNE_MAX_M) *stride |= DBGSOM_PRUNE;
-    else if (probe && M <= PRUNE_MAX_M) *stride |= DBGSOM_PRUNE_PROBE;
+    if (!planes && M <= PRUNE_MAX_M) *stride |= DBGSOM_PRUNE | (retry ? DBGSOM_PRUNE_RETRY : 0);
+    else if (probe && M <= PRUNE_MAX_M) *stride |= DBGSOM_PRUNE_PROBE | (retry ? DBGSOM_PRUNE_RETRY : 0);
 }
 
 // prototypes: make W (host, or the resident ones) the consumed matrix Wb[cur]; norms into ww
@@ -462,7 +466,8 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
         TRY(launch_status("row_shift_kernel"));
         dbgsom_filter_hint_bound(c->dist.as<double>(), c->shiftb.as<double>());
     }
-    filter_call_args(c->planes_used, c->last_probed, M, &stride, &planes_arg);
+    c->last_retry = c->prune_retry;
+    filter_call_args(c->planes_used, c->last_probed, c->prune_retry, M, &stride, &planes_arg);
     TRY(dbgsom_bmu_filtered(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), s.planes.p, W, M,
                             c->ww.as<double>(), prev_idx, order, stride, planes_arg, round_f32, idx,
                             dist, ws.p, ws.cap, c->stream));
@@ -595,12 +600,31 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
 }
 
 // after an epoch has completed: look at how long the candidate lists were, decide what comes next
-void update_policy(dbgsom_ctx *c, double list_sum, double probe_sum, int64_t nb, int64_t M) {
+void update_policy(dbgsom_ctx *c, double list_sum, double probe_sum, double retry_groups, int64_t nb, int64_t M) {
     if (!c->last_filtered) { c->last_mean = NAN; return; }
+    // Workgroups of the pruning form whose lists came out long (poor cheap seeds) while the re-seeding
+    // passes were off: what this call measured of arm 0 is not what the arm costs.  Turn them on and
+    // measure again -- the same arm once more, or another counting-only launch.
+    bool again = false;
+    if (c->planes_used == 0 || c->last_probed) {
+        const bool need = retry_groups > 0.0;
+        if (need && !c->last_retry && !c->last_hinted && !c->last_seed_full) {   // (cheap seeds: re-seeding can help)
+            c->prune_retry = true;
+            if (c->planes_used == 0) {
+                c->last_mean = nb ? list_sum / (double)nb : 0.0;
+                return;
+            }
+            c->last_probed = false;
+            again = true;
+        } else if (!c->last_hinted && !c->last_seed_full) {
+            c->prune_retry = need;
+        }
+    }
     const double mean = nb ? list_sum / (double)nb : 0.0;
     c->last_mean = mean;
     c->last_probe_mean = c->last_probed && nb ? probe_sum / (double)nb : NAN;
     adapt_arms(c, mean, M, nb * 128);
+    if (again) c->probe_next = true;
     if (c->algorithm == DBGSOM_ALG_AUTO) {
         // (the cheapest arm known so far, not an arm that is only being looked at)
         if (c->best_mean > (double)c->max_mean_candidates) {  // exponential back-off, capped
@@ -693,7 +717,7 @@ int smooth_and_fetch(dbgsom_ctx *c, int64_t M, double sigma, int layout, int fla
     mark(c, 3);
     // the epoch's small results: one kernel writes them into mapped page-locked memory, one stream
     // synchronisation
-    TRY(c->tail.reserve((size_t)(2 * M + 4) * 8));
+    TRY(c->tail.reserve((size_t)(2 * M + 5) * 8));
     double *tail = c->tail.as<double>();
     const unsigned long long *list_sum =
         c->last_filtered ? dbgsom_filter_count_sum_ptr(c->filt_ws.p, s.N, dp, M) : nullptr;
@@ -848,6 +872,7 @@ int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
     else if (!strcmp(name, "filter_backoff")) *v = c->filter_backoff;
     else if (!strcmp(name, "plane_hold")) *v = c->plane_hold;
     else if (!strcmp(name, "seed_mode")) *v = c->seed_mode;
+    else if (!strcmp(name, "prune_retry")) *v = c->prune_retry ? 1 : 0;
     else if (!strcmp(name, "w_upload_calls")) *v = c->w_up_calls;
     else if (!strcmp(name, "w_upload_bytes")) *v = c->w_up_bytes;
     else if (!strcmp(name, "w_download_calls")) *v = c->w_down_calls;
@@ -888,6 +913,7 @@ static void reset_training_state(dbgsom_ctx *c) {
     c->plane_hold = 0;
     c->seed_mode = 0;
     c->probe_next = c->last_probed = false;
+    c->prune_retry = false;
     c->dist_bound_valid = false;
     c->last_filtered = false;
     c->last_mean = NAN;
@@ -1087,7 +1113,7 @@ int dbgsom_ctx_bmu_query(dbgsom_ctx *c, const void *Xq_host, int x_dtype, int64_
             if ((rc = ensure_planes(c, s))) break;
             if ((rc = fws.reserve_zeroed(dbgsom_bmu_filtered_workspace_bytes(Nq, dp, M), c->stream))) break;
             int stride = c->seed_stride, planes = 1;
-            filter_call_args(planes_for_call(c), false, M, &stride, &planes);
+            filter_call_args(planes_for_call(c), false, c->prune_retry, M, &stride, &planes);
             rc = dbgsom_bmu_filtered(s.Xb, s.bdtype, Nq, dp, dp, s.xx.as<double>(), s.planes.p, Wq.as<double>(), M,
                                      wwq.as<double>(), nullptr, nullptr, stride, planes, round_f32,
                                      iq.as<int64_t>(), dq.as<double>(), fws.p, fws.cap, c->stream);
@@ -1152,7 +1178,8 @@ int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f
                               idx, idx_host, dist_host);
         if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) break;
         c->last_frozen = (flags & DBGSOM_EPOCH_FROZEN) != 0;
-        update_policy(c, c->tail.as<double>()[2 * M + 2], c->tail.as<double>()[2 * M + 3], (s.N + 127) / 128, M);
+        update_policy(c, c->tail.as<double>()[2 * M + 2], c->tail.as<double>()[2 * M + 3], c->tail.as<double>()[2 * M + 4],
+                      (s.N + 127) / 128, M);
     } while (0);
     if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) { (void)hipStreamSynchronize(c->stream); c->hint_valid = false; }
     return rc;

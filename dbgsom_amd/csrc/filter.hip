@@ -32,7 +32,8 @@ constexpr int FNT = 512;          // threads per sweep workgroup (8 wavefronts)
 constexpr int FSTAGES = 3;
 constexpr int PREPASS_KTILES = 3;  // k-tiles the seed pre-pass samples (tile_select_kernel picks them)
 constexpr int SCHED_BINS = 16;     // launch-order bins of the exact stage (section 2b)
-constexpr int SCHED_CTR = 2 * SCHED_BINS + 10;  // bin counts | cursors | [start, n] of classes 3, 2, 1 | sum of list lengths (u64) | the same of a counting-only pruning launch (u64)
+constexpr int SCHED_RETRY = 2 * SCHED_BINS + 10;  // u64: workgroups of the pruning form whose lists came out long (re-seeded, 2c)
+constexpr int SCHED_CTR = 2 * SCHED_BINS + 12;  // bin counts | cursors | [start, n] of classes 3, 2, 1 | sum of list lengths (u64) | the same of a counting-only pruning launch (u64)
 constexpr int SCHED_SUM = 2 * SCHED_BINS + 6;  // (8-byte aligned: the counters sit on a 256-byte boundary)
 constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
 #ifndef SUBSET_EXPERIMENT
@@ -204,6 +205,9 @@ __device__ __forceinline__ void wtables_body(const double *__restrict__ tw, cons
         // (the seed pre-pass only needs SOME seed: plain float32, no guard)
         o.tab32[2 * (size_t)Mpad + j] = in_sub ? (float)yy_part[j] : 0.f;
         o.tab32[3 * (size_t)Mpad + j] = (float)(csub * 65536.0);
+        // the same plain form for EVERY prototype and the whole row: the re-seed pass of section 2c
+        o.tab32[4 * (size_t)Mpad + j] = j < M ? (float)o.ww[j] : 0.f;
+        o.tab32[5 * (size_t)Mpad + j] = j < M ? (float)(2.0 * tw[j] * 65536.0 / (FQ * FQ) * 65536.0) : 0.f;
         if (j >= M) {
             o.ctab[j] = 0.0; o.yypad[j] = 0.0; o.ictab[j] = 0.0; o.yctab[j] = 0.0;
             o.tab32[j] = 0.f; o.tab32[(size_t)Mpad + j] = 0.f;
@@ -1087,7 +1091,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, int w_rows,
     int64_t *__restrict__ seed, int jstride, int nkt_used, const int32_t *__restrict__ kt_sel,
-    uint32_t *__restrict__ sched_ctr, const float *__restrict__ chk_g) {
+    uint32_t *__restrict__ sched_ctr, const float *__restrict__ chk_g,
+    const int32_t *__restrict__ retry_groups, const unsigned long long *__restrict__ retry_len) {
     using L = Sweep4Lds;
     // NW wavefronts as 2 (samples) x WJ (prototypes), wavefront tile 64 x 32 JT: 4 -> 64 x 128,
     // 8 -> 64 x 64 (64 accumulator registers: <= 128 VGPRs, four wavefronts per SIMD)
@@ -1110,10 +1115,16 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave / WJ, wj = wave % WJ;
     const int lc = lane & 31, lh = lane >> 5;
-    const int64_t p0 = (int64_t)blockIdx.x * 128;
+    // (MODE 1 re-seeding the listed 128-sample workgroups of a bucket order: section 2c)
+    int64_t group = blockIdx.x;
+    if (retry_groups) {
+        if ((unsigned long long)blockIdx.x >= *retry_len) return;
+        group = retry_groups[blockIdx.x];
+    }
+    const int64_t p0 = group * 128;
     const int nwords = (M + 31) / 32;
 
-    auto sample_at = [&](int64_t p) -> int64_t { return (MODE == 0) ? (int64_t)order[p] : p; };
+    auto sample_at = [&](int64_t p) -> int64_t { return (MODE == 0 || order) ? (int64_t)order[p] : p; };
     // every thread's own loads first (see sweep_i8_kernel)
     int64_t i_dr[XI];
     int dc[XI];
@@ -1552,7 +1563,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
                 const int oj = sj[w * 128 + tid];
                 if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
             }
-            seed[p0 + tid] = (int64_t)bj;
+            seed[sample_at(p0 + tid)] = (int64_t)bj;
         }
         return;
     }
@@ -1748,14 +1759,25 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order, const float *__restrict__ gap, int ldg,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, uint32_t *__restrict__ sched_ctr,
     unsigned long long *__restrict__ sum_out, int count_only, const double *__restrict__ dist_prev,
-    const double *__restrict__ shift) {
+    const double *__restrict__ shift, int32_t *__restrict__ retry_groups, unsigned long long *__restrict__ retry_len,
+    int retry_mode, uint32_t retry_above) {
+    // retry_mode 1: a workgroup whose list comes out longer than retry_above is not final -- its id goes
+    // to retry_groups (its samples' seeds were poor: a cluster none of whose prototypes is in the cheap
+    // pre-pass's subset sends its samples to seeds in OTHER clusters, and twice that distance rules
+    // nothing out); the launcher re-seeds those workgroups against every prototype and calls again with
+    // retry_mode 2: the listed workgroups only, final whatever comes out.
     __shared__ int prev_s[128], run_p[128];
     __shared__ int64_t samp_s[128];
     __shared__ unsigned long long bound_s[128], run_t[128];  // non-negative doubles by their bit patterns
     __shared__ uint32_t mask[PRUNE_MAX_M / 32];
     __shared__ int misc[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t p0 = (int64_t)blockIdx.x * 128;
+    int64_t group = blockIdx.x;
+    if (retry_mode == 2) {
+        if ((unsigned long long)blockIdx.x >= *retry_len) return;
+        group = retry_groups[blockIdx.x];
+    }
+    const int64_t p0 = group * 128;
     const int nwords = (M + 31) / 32;
     const unsigned long long INF_BITS = 0x7ff0000000000000ull;
     for (int w = tid; w < nwords; w += 256) mask[w] = 0u;
@@ -1879,7 +1901,6 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
         const int nrun = misc[1];
         // a wave owns its mask words: 64 prototypes at a time against every run, four rows of the gap
         // matrix in flight (one at a time the workgroup waited for L2 once per run and step)
-#pragma unroll 2
         for (int j0 = wave * 64; j0 < M; j0 += 256) {
             const int j = j0 + lane;
             const int jc = j < M ? j : M - 1;
@@ -1913,7 +1934,7 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
     __syncthreads();
     if (wave == 0) {  // compact the marked prototypes, ascending (as the sweeps do)
         uint32_t base = 0;
-        uint16_t *out = ulist + (size_t)blockIdx.x * ulist_stride;
+        uint16_t *out = ulist + (size_t)group * ulist_stride;
         for (int w0 = 0; w0 < nwords; w0 += 64) {
             const int w = w0 + lane;
             uint32_t bits = (w < nwords) ? mask[w] : 0u;
@@ -1933,11 +1954,16 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
             base += __shfl(pre, 63, 64);
         }
         if (lane == 0) {
-            if (!count_only) {
-                ucount[blockIdx.x] = base;
-                atomicAdd(&sched_ctr[sched_bin(base)], 1u);
+            if (retry_mode == 1 && base > retry_above) {
+                retry_groups[atomicAdd(retry_len, 1ull)] = (int32_t)group;
+            } else {
+                if (retry_mode == 0 && base > retry_above) atomicAdd(retry_len, 1ull);  // (only counted: for the policy)
+                if (!count_only) {
+                    ucount[group] = base;
+                    atomicAdd(&sched_ctr[sched_bin(base)], 1u);
+                }
+                atomicAdd(sum_out, (unsigned long long)base);
             }
-            atomicAdd(sum_out, (unsigned long long)base);
         }
     }
 }
@@ -2246,7 +2272,7 @@ struct FilterWs {
     double *wscale, *wl1;  // M each
     double *wn0;           // M: sum of the squared top digits of a row (section 2c)
     double *ctab, *yypad, *ctab_sub, *yy_sub, *ictab, *yctab, *yy_part, *summary;
-    float *tab32;        // 4 x Mpad float32: [yctab | ictab | yy_sub | ctab_sub 2^16] for the 2-per-CU sweep's epilogue
+    float *tab32;        // 6 x Mpad float32: [yctab | ictab | yy_sub | ctab_sub 2^16 | yy | ctab 2^16] for the 2-per-CU sweep's epilogue
     float *chk32;        // Mpad / 256 x 4 float32: [min yctab, min ictab, max ictab, -] per 256-prototype chunk
     double *tile_score;  // dpad / 64
     double *tile_part;   // TS_RB x 2 x dpad
@@ -2258,6 +2284,7 @@ struct FilterWs {
     int64_t *seed;     // N   arg-min of the coarse pre-pass (when the caller has no previous winners)
     int32_t *order;    // N   bucket order of the samples by seed
     float *gap;        // Mg x Mg lower bounds of the squared distances between prototypes (2c); M <= PRUNE_MAX_M
+    int32_t *retry;    // nb: workgroups of the pruning form to be re-seeded
     int64_t Mg;        // its leading dimension: M rounded up to 64
     void *sort_ws;
     int64_t nb, Mpad;
@@ -2273,7 +2300,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t o8 = take((size_t)Mpad * 8), o9 = take((size_t)Mpad * 8);
     const size_t o10 = take((size_t)Mpad * 8), o11 = take((size_t)Mpad * 8), o12 = take((size_t)Mpad * 8);
     const size_t o13 = take((size_t)(dpad / FKT) * 8), o14 = take((size_t)SW_MAX_KT * 4);
-    const size_t o18 = take((size_t)4 * Mpad * 4), o19 = take((size_t)(Mpad / 256) * 16);
+    const size_t o18 = take((size_t)6 * Mpad * 4), o19 = take((size_t)(Mpad / 256) * 16);
     const size_t o15 = take((size_t)TS_RB * 2 * dpad * 8);
     const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
@@ -2281,7 +2308,9 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t o16 = take((size_t)nb * 4), o17 = take((size_t)SCHED_CTR * 4);
     const int64_t Mg = (M + 63) / 64 * 64;
     const size_t o20 = take(M <= PRUNE_MAX_M ? (size_t)Mg * Mg * 4 : 0);
+    const size_t o21 = take((size_t)nb * 4);
     if (f) {
+        f->retry = (int32_t *)(base + o21);
         f->gap = M <= PRUNE_MAX_M ? (float *)(base + o20) : nullptr; f->Mg = Mg;
         f->tickets = (uint32_t *)(base + otk);
         f->sched = (int32_t *)(base + o16); f->sched_ctr = (uint32_t *)(base + o17);
@@ -2448,7 +2477,10 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     // DBGSOM_PRUNE_PROBE: the sweep as usual, and beside it what DBGSOM_PRUNE's lists would add up to
     const bool prune = (seed_stride & DBGSOM_PRUNE) != 0 && M <= PRUNE_MAX_M;
     const bool prune_probe = !prune && (seed_stride & DBGSOM_PRUNE_PROBE) != 0 && M <= PRUNE_MAX_M;
-    seed_stride &= ~(DBGSOM_PRUNE | DBGSOM_PRUNE_PROBE);
+    // DBGSOM_PRUNE_RETRY (stateless searches with cheap seeds): workgroups whose pruned lists come out
+    // long are re-seeded against every prototype and pruned again (two more short launches)
+    const bool prune_retry = (seed_stride & DBGSOM_PRUNE_RETRY) != 0 && !seed_full && !prev_idx_dev;
+    seed_stride &= ~(DBGSOM_PRUNE | DBGSOM_PRUNE_PROBE | DBGSOM_PRUNE_RETRY);
     seed_stride = seed_full ? 1 : seed_stride;
     DBGSOM_REQUIRE(seed_stride >= 0 && seed_stride <= 64, "seed_stride outside [0, 64]");
     DBGSOM_REQUIRE(sweep_planes >= 0 && sweep_planes <= 3, "sweep_planes must be 0 .. 3");
@@ -2521,7 +2553,8 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                                xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.tab32 + 2 * (size_t)f.Mpad,
                                f.tab32 + 3 * (size_t)f.Mpad, f.yy_sub,
                                f.ctab_sub, f.summary, Msub, (const int64_t *)nullptr, (const int32_t *)nullptr,
-                               f.ulist, (int)f.Mpad, f.ucount, Msubpad, f.seed, seed_stride, nkt_used, f.kt_sel, f.sched_ctr, f.chk32);
+                               f.ulist, (int)f.Mpad, f.ucount, Msubpad, f.seed, seed_stride, nkt_used, f.kt_sel, f.sched_ctr, f.chk32,
+                               (const int32_t *)nullptr, (const unsigned long long *)nullptr);
         else if (sweep_planes == 1)
             hipLaunchKernelGGL((sweep_i8_kernel<1, 1, 2>), dim3((unsigned)f.nb), dim3(FNT), 0, s, xb.planes,
                            xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt_sub, f.yy_sub, f.ctab_sub,
@@ -2551,10 +2584,25 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         hipLaunchKernelGGL(proto_gap_kernel, dim3(gt, gt), dim3(64), 0, s, f.wt, (int)f.Mpad, dpad, (int)M, (int)d,
                            f.wscale, f.wn0, f.gap, (int)f.Mg);
         unsigned long long *sum = reinterpret_cast<unsigned long long *>(f.sched_ctr + SCHED_SUM) + (prune ? 0 : 1);
+        unsigned long long *rlen = reinterpret_cast<unsigned long long *>(f.sched_ctr + SCHED_RETRY);
+        const uint32_t retry_above = (uint32_t)(M / 8 > 96 ? M / 8 : 96);
+        // (the count is kept either way: the engine turns the re-seeding on when a call reports any)
         hipLaunchKernelGGL(prune_mark_kernel, dim3((unsigned)f.nb), dim3(256), 0, s, xb.planes, xb.scale, xx_dev,
                            N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, f.summary, (int)M, prev_idx_dev,
                            order_dev, f.gap, (int)f.Mg, f.ulist, (int)f.Mpad, f.ucount, f.sched_ctr, sum,
-                           prune ? 0 : 1, g_hint_shift ? g_hint_dist : (const double *)nullptr, g_hint_shift);
+                           prune ? 0 : 1, g_hint_shift ? g_hint_dist : (const double *)nullptr, g_hint_shift,
+                           f.retry, rlen, prune_retry ? 1 : 0, retry_above);
+        if (prune_retry) {
+            // every prototype, every feature, one digit product, for the listed workgroups only
+            S4_LAUNCH(1, f.nb, xb.planes, xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt,
+                      f.tab32 + 4 * (size_t)f.Mpad, f.tab32 + 5 * (size_t)f.Mpad, f.yypad, f.ctab, f.summary, (int)M,
+                      (const int64_t *)nullptr, order_dev, f.ulist, (int)f.Mpad, f.ucount, (int)f.Mpad, f.seed, 1, 0,
+                      (const int32_t *)nullptr, f.sched_ctr, f.chk32, (const int32_t *)f.retry, (const unsigned long long *)rlen);
+            hipLaunchKernelGGL(prune_mark_kernel, dim3((unsigned)f.nb), dim3(256), 0, s, xb.planes, xb.scale, xx_dev,
+                               N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, f.summary, (int)M, prev_idx_dev,
+                               order_dev, f.gap, (int)f.Mg, f.ulist, (int)f.Mpad, f.ucount, f.sched_ctr, sum,
+                               prune ? 0 : 1, (const double *)nullptr, (const double *)nullptr, f.retry, rlen, 2, retry_above);
+        }
     }
     g_hint_dist = g_hint_shift = nullptr;
     // one digit product: 4-wavefront workgroups unless DBGSOM_SWEEP_SHAPE=8 (see dbgsom_sweep_shape)
@@ -2566,7 +2614,8 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         S4_LAUNCH(0, f.nb, xb.planes, xb.scale,
                            xb.l1, xx_dev, N, (int)d, dpad, f.wt, f.tab32, f.tab32 + (size_t)f.Mpad, f.yypad, f.ctab,
                            f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
-                           (int)f.Mpad, (int64_t *)nullptr, 1, 0, (const int32_t *)nullptr, f.sched_ctr, f.chk32);
+                           (int)f.Mpad, (int64_t *)nullptr, 1, 0, (const int32_t *)nullptr, f.sched_ctr, f.chk32,
+                           (const int32_t *)nullptr, (const unsigned long long *)nullptr);
     } else if (sweep_planes == 1) {  // one digit product: 128 x 512 tile (128 x 256 for small maps)
         if (M > 256) DBGSOM_SWEEP(1, 4); else DBGSOM_SWEEP(1, 2);
     } else if (sweep_planes == 3)

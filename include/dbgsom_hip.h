@@ -60,6 +60,10 @@ extern "C" {
  * dbgsom_ctx_epoch_info / the engine's policy reads (what DBGSOM_PRUNE would cost, without paying it). */
 #define DBGSOM_PRUNE 0x200
 #define DBGSOM_PRUNE_PROBE 0x400
+/* with either of the two, in a stateless search with the cheap seed pre-pass: 128-sample workgroups
+ * whose pruned lists come out longer than max(96, M / 8) -- their seeds were poor -- are seeded again
+ * against every prototype and pruned again (two more short launches) */
+#define DBGSOM_PRUNE_RETRY 0x800
 
 /* prototype-count limit of the accumulate step (per-block LDS histogram) */
 #define DBGSOM_MAX_PROTOTYPES 16000
