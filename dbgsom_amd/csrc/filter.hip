@@ -1727,6 +1727,14 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
             }
     }
     const double root_d = sqrt((double)d) * (1.0 + 1e-12);
+    // the tile's 64 column prototypes: scale and digit norm once, through LDS (every lane needs 32 of them)
+    __shared__ double tj_s[64], bj_s[64];
+    {
+        const int j = jb + lane;
+        tj_s[lane] = j < M ? tw[j] : 0.0;
+        bj_s[lane] = j < M ? wn0[j] : 0.0;
+    }
+    __syncthreads();
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int p = pb + it * 32 + lc;
@@ -1737,11 +1745,13 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int j = jb + jt * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+                const int jl = jt * 32 + 4 * lh + (r & 3) + 8 * (r >> 2), j = jb + jl;
                 if (!pok || j >= M) continue;
-                const double tj = tw[j], Bj = wn0[j], Pv = (double)P[jt][it][r];
+                const double tj = tj_s[jl], Bj = bj_s[jl], Pv = (double)P[jt][it][r];
                 const double sq = tp * tp * Bp + tj * tj * Bj, cr = 2.0 * tp * tj * Pv;
-                const double dh2 = ((sq - cr) - 1e-12 * (sq + fabs(cr))) / 16129.0;
+                // (the division by 127^2 as a product by its rounded reciprocal: 2^-53 relative, far
+                //  inside the 1e-12 margins taken just before and after)
+                const double dh2 = ((sq - cr) - 1e-12 * (sq + fabs(cr))) * (1.0 / 16129.0);
                 const double lo = (dh2 > 0.0 ? sqrt(dh2) * (1.0 - 1e-12) : 0.0) - (ep + root_d * tj * PLANE0_ERR);
                 const double v = lo > 0.0 ? lo * lo * (1.0 - 1e-6) : 0.0;
                 // (anything that is not a positive finite number: no gap known)
@@ -1899,30 +1909,44 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
         }
         __syncthreads();
         const int nrun = misc[1];
-        // a wave owns its mask words: 64 prototypes at a time against every run, four rows of the gap
-        // matrix in flight (one at a time the workgroup waited for L2 once per run and step)
-        for (int j0 = wave * 64; j0 < M; j0 += 256) {
-            const int j = j0 + lane;
-            const int jc = j < M ? j : M - 1;
-            bool keep = false;
+        // a wave owns its mask words: four steps of 64 prototypes against four runs at a time -- 16 rows
+        // of the gap matrix in flight per lane (one at a time the workgroup waited for L2 once per run and step)
+        constexpr int JU = 4;
+        for (int jb = wave * 64; jb < M; jb += 256 * JU) {
+            bool keep[JU] = {false, false, false, false};
             for (int r = 0; r < nrun; r += 4) {
-                float g[4];
                 int pr[4];
                 double T[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int rr = r + u < nrun ? r + u : r;
-                    pr[u] = run_p[rr];
-                    T[u] = __longlong_as_double((long long)run_t[rr]);
-                    g[u] = gap[(size_t)pr[u] * ldg + jc];
+                for (int v = 0; v < 4; ++v) {
+                    const int rr = r + v < nrun ? r + v : r;
+                    pr[v] = run_p[rr];
+                    T[v] = __longlong_as_double((long long)run_t[rr]);
+                }
+                float g[JU][4];
+#pragma unroll
+                for (int u = 0; u < JU; ++u) {
+                    const int j = jb + 256 * u + lane;
+                    const int jc = j < M ? j : M - 1;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) g[u][v] = gap[(size_t)pr[v] * ldg + jc];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) keep |= (j == pr[u]) || !((double)g[u] >= T[u]);
+                for (int u = 0; u < JU; ++u) {
+                    const int j = jb + 256 * u + lane;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) keep[u] |= (j == pr[v]) || !((double)g[u][v] >= T[v]);
+                }
             }
-            const uint64_t b = __builtin_amdgcn_ballot_w64(keep && j < M);
-            if (lane == 0) {
-                mask[j0 >> 5] = (uint32_t)b;
-                if ((j0 >> 5) + 1 < nwords) mask[(j0 >> 5) + 1] = (uint32_t)(b >> 32);
+#pragma unroll
+            for (int u = 0; u < JU; ++u) {
+                const int j0 = jb + 256 * u;
+                if (j0 >= M) break;
+                const uint64_t b = __builtin_amdgcn_ballot_w64(keep[u] && j0 + lane < M);
+                if (lane == 0) {
+                    mask[j0 >> 5] = (uint32_t)b;
+                    if ((j0 >> 5) + 1 < nwords) mask[(j0 >> 5) + 1] = (uint32_t)(b >> 32);
+                }
             }
         }
     } else {

@@ -259,3 +259,27 @@ def test_full_size_c3_and_c2_properties():
             assert probes[0] < 0.1 * M and np.isnan(probes[-1]), probes
             fi.release()
         hip.release()
+
+
+def test_whole_fit_with_the_pruning_search_equals_the_fit_with_the_all_pairs_search():
+    """A growing map trained through `SomVQ.fit` with the search forced to the pruning form (no
+    sweep; seeds = the previous epoch's winners, seed distances from that epoch's exact distances
+    plus the prototypes' shift, growth steps in between) ends in the map the all-pairs search gives:
+    same neurons, bit-identical prototypes and labels."""
+    from dbgsom_amd import SomVQ
+    from dbgsom_amd.backend import HipBackend
+
+    X, _ = gi.blobs_f32(60_000, 64, 5, n_centers=300)
+    kw = dict(random_state=0, max_neurons=400, n_iter=120, spreading_factor=0.9, coarse_training_frac=0.9,
+              convergence_iter=2)
+    ref = SomVQ(backend=HipBackend(algorithm="exact"), **kw).fit(X)
+    be = HipBackend(algorithm="filtered_hint")   # (`auto` would back off to the all-pairs kernel on the young map)
+    be.sweep_planes = 4
+    est = SomVQ(backend=be, **kw).fit(X)
+    assert len(ref.neurons_) > 300, len(ref.neurons_)          # the filter takes over above 128 prototypes
+    assert est.neurons_ == ref.neurons_ and est.n_iter_ == ref.n_iter_
+    assert np.array_equal(est.weights_, ref.weights_)
+    assert np.array_equal(est.labels_, ref.labels_)
+    assert est.quantization_error_ == ref.quantization_error_ and est.topographic_error_ == ref.topographic_error_
+    pruned = [e for e in be.filter_log if e[0] == "filtered" and e[2] == 0]
+    assert len(pruned) >= 40, be.filter_log[-10:]

@@ -998,3 +998,33 @@ def test_pruning_reseeds_workgroups_whose_cheap_seeds_missed_their_cluster(o):
     assert retry[:2] == [1, 1] and means[1] < 0.75 * means[0], (means, retry)
     assert np.bincount(q.winners[lab == 0], minlength=M)[wl != 0].sum() == 0     # cluster 0 is won by its own
     ex.release(); fi.release()
+
+
+@pytest.mark.parametrize("N,d,M", [(3000, 32, 8192), (3000, 32, 9000), (100, 48, 200), (129, 16, 129),
+                                   (5000, 4096, 300), (20_000, 17, 1000)])
+def test_pruning_at_the_edges_of_its_shapes(N, d, M):
+    """The pruning form takes maps of up to 8192 prototypes (its gap matrix is 4 M^2 bytes); larger
+    ones keep the one-product sweep.  Fewer samples than one workgroup, one prototype tile, very long
+    rows, a feature count that is padded, a map that GROWS between two hinted epochs (the prototype
+    shifts then cover the old rows only): winners, distances and new prototypes are those of the
+    all-pairs kernel, bit for bit."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(N + d + M)
+    X = (rng.normal(size=(N, d)) + 2.0 * rng.integers(0, 5, size=(N, 1))).astype(np.float32)
+    W = (X[rng.choice(N, M, replace=M > N)] + 1e-3 * rng.normal(size=(M, d))).astype(np.float64)
+    ex = HipBackend(algorithm="exact").load(X)
+    fi = HipBackend(algorithm="filtered").load(X)
+    fi.sweep_planes = 4
+    Ms = [M, M, min(M + 7, 16000)] if M < 9000 else [M, M]
+    for e, Me in enumerate(Ms):
+        if Me > W.shape[0]:   # growth: seven more prototypes, the old ones nudged
+            W = np.concatenate([W + 1e-4 * rng.normal(size=W.shape), X[rng.choice(N, Me - W.shape[0])].astype(np.float64)])
+        hop = np.zeros((Me, Me))
+        re_ = ex.epoch(W, hop, 1.0, 1e-3, "compact", True)
+        rf = fi.epoch(W, hop, 1.0, 1e-3, "compact", True)
+        assert fi.filter_log[-1][0] == "filtered" and fi.filter_log[-1][2] == (0 if Me <= 8192 else 1)
+        assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances)
+        assert np.array_equal(rf.new_weights, re_.new_weights, equal_nan=True)
+        fi.algorithm = "filtered_hint"   # from the second epoch on: seeds = the previous winners
+    ex.release(); fi.release()
