@@ -923,11 +923,12 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                                 const double Tp = sweep_T_scaled<PLANES>(acc[jt][it][0][r], acc[jt][it][L1][r],
                                                                          acc[jt][it][L2][r]);
 #if SWEEP_EXPERIMENT & 512
-                                const uint64_t b1 = __builtin_amdgcn_ballot_w64((A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp);
+                                const uint64_t b1 = __builtin_amdgcn_ballot_w64(!((A_i[it] * c4[i] + y4[i]) > s_i[it] * Tp));
                                 npass += __popcll(b1);
                                 pass |= b1;
 #else
-                                pass |= __builtin_amdgcn_ballot_w64((A_i[it] * c4[i] + y4[i]) <= s_i[it] * Tp);
+                                // (a NaN marks: a seed that is a NaN row of W gives no bound, not an empty list)
+                                pass |= __builtin_amdgcn_ballot_w64(!((A_i[it] * c4[i] + y4[i]) > s_i[it] * Tp));
 #endif
                             } else {
                                 const double T = combine(acc[jt][it][0][r], acc[jt][it][L1][r], acc[jt][it][L2][r]);
@@ -1675,7 +1676,7 @@ constexpr double PLANE0_ERR = 32897.0 / (127.0 * 65536.0) * (1.0 + 1e-6);
 // k-tile-major top plane (L2-resident), P = D0 . D0
 __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict__ wt, int w_rows, int dpad, int M, int d,
                                                        const double *__restrict__ tw, const double *__restrict__ wn0,
-                                                       float *__restrict__ gap, int ldg) {
+                                                       const double *__restrict__ ww, float *__restrict__ gap, int ldg) {
     const int lane = threadIdx.x, lc = lane & 31, lh = lane >> 5;
     const int pb = blockIdx.x * 64, jb = blockIdx.y * 64;
     const int nks = dpad / 32;  // dpad is a multiple of 64
@@ -1732,14 +1733,16 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
     {
         const int j = jb + lane;
         tj_s[lane] = j < M ? tw[j] : 0.0;
-        bj_s[lane] = j < M ? wn0[j] : 0.0;
+        // (a row with a NaN or an infinity has digits that mean nothing: 0 |w|^2 turns into a NaN and
+        //  the pair gets "no gap known")
+        bj_s[lane] = j < M ? wn0[j] + 0.0 * ww[j] : 0.0;
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int p = pb + it * 32 + lc;
         const bool pok = p < M;
-        const double tp = pok ? tw[p] : 0.0, Bp = pok ? wn0[p] : 0.0;
+        const double tp = pok ? tw[p] : 0.0, Bp = pok ? wn0[p] + 0.0 * ww[p] : 0.0;
         const double ep = root_d * tp * PLANE0_ERR;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
@@ -1765,7 +1768,7 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
 __global__ __launch_bounds__(256) void prune_mark_kernel(
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx, const double *__restrict__ xx, int64_t N, int d,
     int dpad, const int8_t *__restrict__ wplanes, int w_rows, const double *__restrict__ tw,
-    const double *__restrict__ summary, int M,
+    const double *__restrict__ ww, const double *__restrict__ summary, int M,
     const int64_t *__restrict__ prev, const int32_t *__restrict__ order, const float *__restrict__ gap, int ldg,
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, uint32_t *__restrict__ sched_ctr,
     unsigned long long *__restrict__ sum_out, int count_only, const double *__restrict__ dist_prev,
@@ -1876,7 +1879,8 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
                 const double sv = sx[i], tv = tw[pj];
                 const double sq = sv * sv * (double)ax + tv * tv * (double)aw, cr = 2.0 * sv * tv * (double)a0;
                 const double dh2 = ((sq - cr) + 1e-12 * (sq + fabs(cr))) / 16129.0;
-                const double rho = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xx[i] + yy_max);
+                // (|x_i|^2 or |w_seed|^2 not finite -- a NaN or an infinity in the row: rho is not, and no bound)
+                const double rho = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xx[i] + yy_max) + 0.0 * ww[pj];
                 const double up = hint_up[round] >= 0.0
                                       ? hint_up[round] + sqrt(rho) * (1.0 + 1e-12)
                                       : (dh2 > 0.0 ? sqrt(dh2) * (1.0 + 1e-12) : 0.0) + root_d * (sv + tv) * PLANE0_ERR;
@@ -2606,13 +2610,13 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     if (prune || prune_probe) {
         const unsigned gt = (unsigned)(f.Mg / 64);
         hipLaunchKernelGGL(proto_gap_kernel, dim3(gt, gt), dim3(64), 0, s, f.wt, (int)f.Mpad, dpad, (int)M, (int)d,
-                           f.wscale, f.wn0, f.gap, (int)f.Mg);
+                           f.wscale, f.wn0, ww_dev, f.gap, (int)f.Mg);
         unsigned long long *sum = reinterpret_cast<unsigned long long *>(f.sched_ctr + SCHED_SUM) + (prune ? 0 : 1);
         unsigned long long *rlen = reinterpret_cast<unsigned long long *>(f.sched_ctr + SCHED_RETRY);
         const uint32_t retry_above = (uint32_t)(M / 8 > 96 ? M / 8 : 96);
         // (the count is kept either way: the engine turns the re-seeding on when a call reports any)
         hipLaunchKernelGGL(prune_mark_kernel, dim3((unsigned)f.nb), dim3(256), 0, s, xb.planes, xb.scale, xx_dev,
-                           N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, f.summary, (int)M, prev_idx_dev,
+                           N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, ww_dev, f.summary, (int)M, prev_idx_dev,
                            order_dev, f.gap, (int)f.Mg, f.ulist, (int)f.Mpad, f.ucount, f.sched_ctr, sum,
                            prune ? 0 : 1, g_hint_shift ? g_hint_dist : (const double *)nullptr, g_hint_shift,
                            f.retry, rlen, prune_retry ? 1 : 0, retry_above);
@@ -2623,7 +2627,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                       (const int64_t *)nullptr, order_dev, f.ulist, (int)f.Mpad, f.ucount, (int)f.Mpad, f.seed, 1, 0,
                       (const int32_t *)nullptr, f.sched_ctr, f.chk32, (const int32_t *)f.retry, (const unsigned long long *)rlen);
             hipLaunchKernelGGL(prune_mark_kernel, dim3((unsigned)f.nb), dim3(256), 0, s, xb.planes, xb.scale, xx_dev,
-                               N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, f.summary, (int)M, prev_idx_dev,
+                               N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, ww_dev, f.summary, (int)M, prev_idx_dev,
                                order_dev, f.gap, (int)f.Mg, f.ulist, (int)f.Mpad, f.ucount, f.sched_ctr, sum,
                                prune ? 0 : 1, (const double *)nullptr, (const double *)nullptr, f.retry, rlen, 2, retry_above);
         }

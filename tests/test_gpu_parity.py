@@ -1028,3 +1028,39 @@ def test_pruning_at_the_edges_of_its_shapes(N, d, M):
         assert np.array_equal(rf.new_weights, re_.new_weights, equal_nan=True)
         fi.algorithm = "filtered_hint"   # from the second epoch on: seeds = the previous winners
     ex.release(); fi.release()
+
+
+@pytest.mark.parametrize("planes", [1, 2, 3, 4])
+def test_filtered_search_with_non_finite_prototype_rows(planes):
+    """Dead neurons of the aligned centre layout are NaN rows of W (0/0 like the reference), and a
+    diverged row may hold an infinity.  Such prototypes can never win; every form of the filtered
+    search (sweeps with 1..3 digit planes, pruning without a sweep) must neither pick them nor let
+    their meaningless digit planes rule out a real candidate -- also when a NaN row is the SEED."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(77 + planes)
+    N, d, M = 9000, 80, 300
+    X, _ = gi.blobs_f32(N, d, 9, n_centers=12)
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    W[5] = np.nan
+    W[17, 3] = np.nan
+    W[40, 11] = np.inf
+    W[41] = -np.inf
+    hop = np.zeros((M, M))
+    ex = HipBackend(algorithm="exact").load(X)
+    fi = HipBackend(algorithm="filtered").load(X)
+    fi.sweep_planes = planes
+    q = ex.epoch(W, hop, 1.0, 1e-3, "aligned", True)
+    assert not np.isin(q.winners, [5, 17, 40, 41]).any()
+    for e in range(2):
+        r = fi.epoch(W, hop, 1.0, 1e-3, "aligned", True)
+        assert np.array_equal(r.winners, q.winners) and np.array_equal(r.distances, q.distances), (planes, e)
+        fi.algorithm = "filtered_hint"
+    # previous winners that have become NaN rows since: seeds without a distance
+    bad = q.winners.copy()
+    bad[::3] = 5
+    bad[1::3] = 17
+    fi.set_hint(bad, M)
+    r = fi.epoch(W, hop, 1.0, 1e-3, "aligned", True)
+    assert np.array_equal(r.winners, q.winners) and np.array_equal(r.distances, q.distances), planes
+    ex.release(); fi.release()
