@@ -144,7 +144,8 @@ int dbgsom_smooth(const double *sums_dev, int64_t M, int64_t d, const float *hop
  *                 blocks in which the prototypes differ most) finds a starting
  *                 prototype per sample and the samples are bucketed by it; nothing from an earlier
  *                 call is used.  The seed only sets the candidate threshold: ANY seed gives the
- *                 exact result, a nearer one shorter candidate lists.
+ *                 exact result, a nearer one shorter candidate lists.  DBGSOM_SEED_FULL, DBGSOM_PRUNE,
+ *                 DBGSOM_PRUNE_PROBE and DBGSOM_PRUNE_RETRY (above) are OR-ed into this argument.
  *   sweep_planes: digit planes per operand in the candidate sweep: 3 = six digit products (error
  *                 bound ~1e-6 of |x||w|), 2 = three products (bound ~3e-4, half the MFMA work and
  *                 two thirds of the traffic, somewhat longer candidate lists), 1 = one product
