@@ -582,10 +582,11 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
     // arm 0 is looked at by a counting-only launch beside an arm whose lists are known to be
     // bearable (isotropic data: the whole map survives the triangle inequality -- an exact stage
     // over such lists would cost ten ordinary epochs)
+    // (the launch counts from the seeds of the call it rides on: that call uses the seeds of the arm
+    //  being looked at, with a sweep whose cost is known or about to be)
     if (es >= 0 && ep == 0) {
         c->probe_next = true;
         ep = bp ? bp : 1;
-        if (!isnan(c->arm_known[es][ep])) { es = bs; ep = bp ? bp : 1; }
     }
     if (remeasured)  // a second look at this arm: did it pay?
         c->arm_wait[row][p] = (bs == row && bp == p) ? 16 : (c->arm_wait[row][p] >= 64 ? 128 : 2 * c->arm_wait[row][p]);
