@@ -23,13 +23,17 @@ def main():
     res = {}
     # (1) one epoch of the hot path on a row shard + all-reduce of the [S|K|a|E] sums, for a map
     # small enough for the all-pairs kernel and one that takes the filtered search
-    for tag, (N, d, rows, cols) in {"small": (6001, 40, 5, 6), "filt": (9000, 72, 13, 14)}.items():
+    # ("prune": the same with the filtered search forced to its form without a sweep)
+    for tag, (N, d, rows, cols) in {"small": (6001, 40, 5, 6), "filt": (9000, 72, 13, 14),
+                                    "prune": (9000, 72, 13, 14)}.items():
         X, _ = gi.blobs_f32(N, d, 21)
         M = rows * cols
         W = X[np.random.default_rng(3).choice(N, M, replace=False)].astype(np.float64)
         hop = gi.lattice_hops(rows, cols)
         lo, hi = shard_bounds(N, rank, world)
         be = HipBackend(0).load(X[lo:hi])
+        if tag == "prune":
+            be.sweep_planes = 4
         y = (np.arange(N) % 4).astype(np.int32)
         be.set_labels(y[lo:hi])
         r = be.epoch(W, hop, 1.1, 0.002, "compact", True, n_classes=4)
@@ -42,6 +46,7 @@ def main():
         hits, dens = be.node_statistics(W, 1.3)
         res[f"{tag}_hits"], res[f"{tag}_dens"] = hits, dens
         res[f"{tag}_filtered"] = bool(be.filter_log and be.filter_log[-1][0] == "filtered")
+        res[f"{tag}_planes"] = int(be.filter_log[-1][2]) if res[f"{tag}_filtered"] else -1
         # a winner out of range on ONE rank must fail on EVERY rank (status rides in the reduced buffer)
         bad = r.winners.copy()
         if rank == 0:

@@ -45,7 +45,8 @@ def test_hip_backend_two_ranks_one_gpu(world, tmp_path):
     from oracle import som_oracle as o
 
     res = _run(world, tmp_path)
-    for tag, (N, d, rows, cols) in {"small": (6001, 40, 5, 6), "filt": (9000, 72, 13, 14)}.items():
+    for tag, (N, d, rows, cols) in {"small": (6001, 40, 5, 6), "filt": (9000, 72, 13, 14),
+                                    "prune": (9000, 72, 13, 14)}.items():
         X, _ = gi.blobs_f32(N, d, 21)
         M = rows * cols
         W = X[np.random.default_rng(3).choice(N, M, replace=False)].astype(np.float64)
@@ -62,7 +63,8 @@ def test_hip_backend_two_ranks_one_gpu(world, tmp_path):
         coords = [(i, j) for i in range(rows) for j in range(cols)]
         hits1, dens1 = one.node_statistics(W, 1.3)
         for r in res:
-            assert bool(r[f"{tag}_filtered"]) == (tag == "filt")
+            assert bool(r[f"{tag}_filtered"]) == (tag != "small")
+            assert tag != "prune" or int(r["prune_planes"]) == 0     # no sweep: candidates by pruning
             assert np.array_equal(r[f"{tag}_activations"], r1.activations)
             assert np.array_equal(r[f"{tag}_class_hist"], r1.class_hist)
             np.testing.assert_allclose(r[f"{tag}_new_weights"], r1.new_weights, rtol=1e-12, atol=1e-13)
