@@ -243,8 +243,8 @@ int dbgsom_ctx_destroy(dbgsom_ctx *ctx);
  * 1..3 fixed digit planes of the candidate sweep, 4 = no sweep: candidates from the triangle
  * inequality, DBGSOM_PRUNE), "seed_stride" (0 = library default),
  * "timing" (1: HIP events around the phases of an epoch and the stages of the filter),
- * "filter_min_query_rows", "max_mean_candidates", "graph" (1: replay frozen / resident epochs from
- * a HIP graph).  Readable besides those: "n_samples", "features", "padded_features", "prototypes",
+ * "filter_min_query_rows", "max_mean_candidates", "graph" (reserved: accepted and stored, no effect in this
+ * build -- an epoch is 22-23 back-to-back launches on the context's stream and two forked ones).  Readable besides those: "n_samples", "features", "padded_features", "prototypes",
  * "planes_cached", "planes_used", "hint_valid", "filter_backoff", "plane_hold", "device_bytes", and the
  * PCIe traffic of the prototypes since the context was created: "w_upload_calls" / "w_upload_bytes"
  * (whole matrices host -> HBM), "w_download_calls" / "w_download_bytes", "w_row_writes", "w_row_reads". */
