@@ -245,7 +245,8 @@ int dbgsom_ctx_destroy(dbgsom_ctx *ctx);
  * "timing" (1: HIP events around the phases of an epoch and the stages of the filter),
  * "filter_min_query_rows", "max_mean_candidates", "graph" (reserved: accepted and stored, no effect in this
  * build -- an epoch is 22-23 back-to-back launches on the context's stream and two forked ones).  Readable besides those: "n_samples", "features", "padded_features", "prototypes",
- * "planes_cached", "planes_used", "hint_valid", "filter_backoff", "plane_hold", "device_bytes", and the
+ * "planes_cached", "planes_used" / "planes_next" (0 = no sweep), "seed_mode", "prune_retry", "hint_valid",
+ * "filter_backoff", "plane_hold", "device_bytes", and the
  * PCIe traffic of the prototypes since the context was created: "w_upload_calls" / "w_upload_bytes"
  * (whole matrices host -> HBM), "w_download_calls" / "w_download_bytes", "w_row_writes", "w_row_reads". */
 int dbgsom_ctx_set_option(dbgsom_ctx *ctx, const char *name, int64_t value);
