@@ -623,6 +623,15 @@ def test_large_queries_take_the_filtered_search_and_agree_with_the_all_pairs_ker
     assert big.planes_cached and np.array_equal(ib, ie) and np.array_equal(db, de)
     d2, i2 = big.bmu(W, 2)          # k = 2 stays on the all-pairs kernel
     assert np.array_equal(i2[:, 0], ie)
+    # the same queries with the search forced to its form without a sweep (what a context that has
+    # settled on arm 0 during training runs for predict / the post-fit statistics)
+    for be in (auto, big):
+        be.sweep_planes = 4
+    dp, ip = auto.bmu(W, 1, X)
+    assert np.array_equal(ip, ie) and np.array_equal(dp, de)
+    dp, ip = big.bmu(W, 1)
+    assert np.array_equal(ip, ie) and np.array_equal(dp, de)
+    np.testing.assert_allclose(big.quantization_error(W), de.mean(), rtol=1e-12)
 
 
 def test_filtered_search_with_ties_and_bad_previous_winners(o):
