@@ -20,7 +20,7 @@ ALG_AUTO, ALG_EXACT, ALG_FILTERED, ALG_FILTERED_HINT = 0, 1, 2, 3
 ALGORITHMS = {"auto": ALG_AUTO, "exact": ALG_EXACT, "filtered": ALG_FILTERED,
               "filtered_hint": ALG_FILTERED_HINT}
 EPOCH_FROZEN = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 # int (*)(void *user, double *buf_dev, int64_t count, void *stream)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                 ctypes.c_void_p)
@@ -51,6 +51,7 @@ SIGNATURES = {
                                   _ci, _ci, _ci, _vp, _vp, _vp, _sz, _vp]),
     "dbgsom_bmu_filtered_counts": (_ci, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "dbgsom_bmu_filtered_counts_async": (_ci, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "dbgsom_bmu_filtered_refine_counts": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "dbgsom_sweep_shape": (_ci, [_i64, _i64]),
     "dbgsom_filter_timing": (_ci, [_ci]),
     "dbgsom_bmu_filtered_stage_ms": (_ci, [_vp]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "dbgsom_ctx_subset_create": (_ci, [_vp, _i64, ctypes.POINTER(_vp)]),
     "dbgsom_ctx_epoch_info": (_ci, [_vp, _vp]),
     "dbgsom_ctx_filter_counts": (_ci, [_vp, _vp, _i64]),
+    "dbgsom_ctx_refine_counts": (_ci, [_vp, _vp]),
     "dbgsom_ctx_phase_ms": (_ci, [_vp, _vp]),
 }
 

@@ -284,6 +284,8 @@ class HipBackend(HotPathBackend):
     # the stateless seed pre-pass looks at every seed_stride-th prototype (0 = library default)
     seed_stride = property(lambda self: self._get("seed_stride"),
                            lambda self, v: self._set("seed_stride", v))
+    # per-sample refinement in front of the exact stage of the filtered search (filter.hip 2d)
+    refine = property(lambda self: bool(self._get("refine")), lambda self, v: self._set("refine", bool(v)))
     planes_cached = property(lambda self: bool(self._get("planes_cached")))
     padded_features = property(lambda self: self._get("padded_features"))
 
@@ -584,6 +586,13 @@ class HipBackend(HotPathBackend):
         self._call("dbgsom_ctx_filter_counts", self._ctx, out.ctypes.data, nb)
         return out
 
+    def refine_counts(self):
+        """[(sample, prototype) pairs evaluated exactly, workgroups refined, workgroups left to the
+        matrix-core stage] of the last filtered search."""
+        out = np.zeros(4, dtype=np.uint64)
+        self._call("dbgsom_ctx_refine_counts", self._ctx, out.ctypes.data)
+        return [int(v) for v in out[:3]]
+
     def traffic(self):
         """PCIe traffic of the prototypes since the context was created / last released."""
         keys = ("w_upload_calls", "w_upload_bytes", "w_download_calls", "w_download_bytes",
@@ -674,7 +683,7 @@ class HipBackend(HotPathBackend):
         self._call("dbgsom_ctx_subset_create", self._ctx, int(neuron), ctypes.byref(child))
         return HipBackend(self.device_index, self.algorithm, _ctx=child)
 
-    _SETTABLE = ("algorithm", "sweep_planes", "seed_stride", "timing", "graph",
+    _SETTABLE = ("algorithm", "sweep_planes", "seed_stride", "timing", "graph", "refine",
                  "filter_min_query_rows", "max_mean_candidates")
 
     def release(self):

@@ -106,6 +106,31 @@ size_t bucket_sort_workspace_bytes(int64_t N, int64_t M);
 int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order, void *ws,
                        hipStream_t s);
 const uint32_t *bucket_sort_seg_start(const void *ws, int64_t N, int64_t M);
+// the filtered search with everything the engine may add to the public dbgsom_bmu_filtered call
+struct FilteredCall {
+    const void *X = nullptr;
+    int x_dtype = 0;
+    int64_t N = 0, d = 0, ldx = 0;
+    const double *xx = nullptr;
+    const void *xplanes = nullptr;
+    const double *W = nullptr;
+    int64_t M = 0;
+    const double *ww = nullptr;
+    const int64_t *prev_idx = nullptr;
+    const int32_t *order = nullptr;
+    int seed_stride = 0, sweep_planes = 0, round_f32 = 0;
+    int64_t *idx = nullptr;
+    double *dist = nullptr;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    hipStream_t stream = nullptr;
+    // hinted pruning bound (filter.hip 2c): the previous epoch's exact distances and how far each
+    // prototype has moved since
+    const double *hint_dist = nullptr, *hint_shift = nullptr;
+    // per-sample refinement of the candidate lists (2d): 0 = off, else the longest list it should take
+    int refine_rows = 0;
+};
+int launch_bmu_filtered(const FilteredCall &call);
 size_t smooth_workspace_bytes(int64_t M, int64_t d);
 int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, double sigma,
                   int layout, const double *W_old, double *W_new, double *change_total, void *ws,

@@ -189,7 +189,6 @@ using namespace dbgsom;
 // the device-level ABI the engine drives (defined in filter.hip / stats.hip)
 extern "C" {
 const unsigned long long *dbgsom_filter_count_sum_ptr(const void *workspace_dev, int64_t N, int64_t d, int64_t M);
-void dbgsom_filter_hint_bound(const double *dist_prev_dev, const double *shift_dev);
 size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d);
 size_t dbgsom_bmu_filtered_workspace_bytes(int64_t N, int64_t d, int64_t M);
 }
@@ -236,6 +235,7 @@ struct dbgsom_ctx {
     int seed_stride = 0;
     int timing = 0;
     int use_graph = 0;
+    int refine = 1;  // per-sample refinement in front of the exact stage (filter.hip 2d)
     int64_t filter_min_query_rows = 32768;
     int64_t max_mean_candidates = 320;
     // samples
@@ -457,6 +457,7 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     if (may_probe) c->probe_next = false;
     // seeds = the last epoch's winners, and their exact distances are still around: the pruning
     // bound need not read X for samples whose prototype has hardly moved
+    FilteredCall call;
     if (may_probe && prev_idx && c->dist_bound_valid && dist == c->dist.as<double>() && M <= PRUNE_MAX_M &&
         (c->planes_used == 0 || c->last_probed) && c->Wb[c->distW_buf].p) {
         TRY(c->shiftb.reserve((size_t)M * 8));
@@ -464,13 +465,22 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
         hipLaunchKernelGGL(row_shift_kernel, dim3((unsigned)M), dim3(64), 0, c->stream, W,
                            c->Wb[c->distW_buf].as<double>(), s.dp, s.dp, rows, M, c->shiftb.as<double>());
         TRY(launch_status("row_shift_kernel"));
-        dbgsom_filter_hint_bound(c->dist.as<double>(), c->shiftb.as<double>());
+        call.hint_dist = c->dist.as<double>();
+        call.hint_shift = c->shiftb.as<double>();
     }
     c->last_retry = c->prune_retry;
     filter_call_args(c->planes_used, c->last_probed, c->prune_retry, M, &stride, &planes_arg);
-    TRY(dbgsom_bmu_filtered(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), s.planes.p, W, M,
-                            c->ww.as<double>(), prev_idx, order, stride, planes_arg, round_f32, idx,
-                            dist, ws.p, ws.cap, c->stream));
+    call.X = s.Xb; call.x_dtype = s.bdtype; call.N = s.N; call.d = s.dp; call.ldx = s.dp;
+    call.xx = s.xx.as<double>(); call.xplanes = s.planes.p; call.W = W; call.M = M; call.ww = c->ww.as<double>();
+    call.prev_idx = prev_idx; call.order = order; call.seed_stride = stride; call.sweep_planes = planes_arg;
+    call.round_f32 = round_f32; call.idx = idx; call.dist = dist; call.ws = ws.p; call.ws_bytes = ws.cap;
+    call.stream = c->stream;
+    // the tile of the refinement's first list-length class: what the lists were last time, with some room
+    // (longer lists go to its largest tile, beyond that to the matrix-core stage)
+    int rf_rows = 64;
+    if (c->last_mean == c->last_mean && c->last_filter_M == M) rf_rows = (int)(c->last_mean * 1.25 + 8.0);
+    call.refine_rows = c->refine ? rf_rows : 0;
+    TRY(launch_bmu_filtered(call));
     c->last_filter_M = M; c->last_filter_N = s.N; c->last_filter_d = s.dp; c->last_filter_ws = ws.p;
     return DBGSOM_OK;
 }
@@ -838,6 +848,8 @@ int dbgsom_ctx_set_option(dbgsom_ctx *c, const char *name, int64_t v) {
         TRY(dbgsom_filter_timing(c->timing));
     } else if (!strcmp(name, "graph")) {
         c->use_graph = v != 0;
+    } else if (!strcmp(name, "refine")) {
+        c->refine = v != 0;
     } else if (!strcmp(name, "filter_min_query_rows")) {
         DBGSOM_REQUIRE(v >= 0, "filter_min_query_rows must be >= 0");
         c->filter_min_query_rows = v;
@@ -859,6 +871,7 @@ int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
     else if (!strcmp(name, "seed_stride")) *v = c->seed_stride;
     else if (!strcmp(name, "timing")) *v = c->timing;
     else if (!strcmp(name, "graph")) *v = c->use_graph;
+    else if (!strcmp(name, "refine")) *v = c->refine;
     else if (!strcmp(name, "filter_min_query_rows")) *v = c->filter_min_query_rows;
     else if (!strcmp(name, "max_mean_candidates")) *v = c->max_mean_candidates;
     else if (!strcmp(name, "n_samples")) *v = c->xs.dtype < 0 ? 0 : c->xs.N;
@@ -1468,6 +1481,14 @@ int dbgsom_ctx_filter_counts(dbgsom_ctx *c, uint32_t *counts_host, int64_t n) {
     if (!c->last_filter_ws) { set_error("dbgsom_ctx_filter_counts: no filtered search has run"); return DBGSOM_ESTATE; }
     return dbgsom_bmu_filtered_counts(c->last_filter_ws, c->last_filter_N, c->last_filter_d, c->last_filter_M, counts_host, n,
                                       c->stream);
+}
+
+int dbgsom_ctx_refine_counts(dbgsom_ctx *c, uint64_t *out4) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(out4, "null pointer");
+    if (!c->last_filter_ws) { set_error("dbgsom_ctx_refine_counts: no filtered search has run"); return DBGSOM_ESTATE; }
+    return dbgsom_bmu_filtered_refine_counts(c->last_filter_ws, c->last_filter_N, c->last_filter_d, c->last_filter_M, out4,
+                                             c->stream);
 }
 
 int dbgsom_ctx_phase_ms(dbgsom_ctx *c, double *ms8) {

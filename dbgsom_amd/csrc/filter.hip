@@ -27,6 +27,7 @@
 namespace dbgsom {
 
 constexpr double FQ = 8323072.0;  // 127 * 2^16
+constexpr double F16 = 32512.0;   // 127 * 2^8: scale of the top two digit planes taken as one 16-bit digit
 constexpr int FKT = 64;           // bytes (= features) per plane row per LDS stage
 constexpr int FNT = 512;          // threads per sweep workgroup (8 wavefronts)
 constexpr int FSTAGES = 3;
@@ -35,6 +36,8 @@ constexpr int SCHED_BINS = 16;     // launch-order bins of the exact stage (sect
 constexpr int SCHED_RETRY = 2 * SCHED_BINS + 10;  // u64: workgroups of the pruning form whose lists came out long (re-seeded, 2c)
 constexpr int SCHED_CTR = 2 * SCHED_BINS + 12;  // bin counts | cursors | [start, n] of classes 3, 2, 1 | sum of list lengths (u64) | the same of a counting-only pruning launch (u64)
 constexpr int SCHED_SUM = 2 * SCHED_BINS + 6;  // (8-byte aligned: the counters sit on a 256-byte boundary)
+constexpr int RF_CTR = 4;  // u64 counters of the refinement (2d): pairs | refined workgroups | left to the MFMA stage | -
+static_assert(SCHED_CTR % 2 == 0, "the 64-bit counters of the refinement sit behind the schedule's");
 constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
 #ifndef SUBSET_EXPERIMENT
 // Diagnostic builds of this file (never the shipped library): -DSUBSET_EXPERIMENT=<bits> /
@@ -59,13 +62,23 @@ inline int64_t filter_dpad(int64_t d) {
 }
 
 // ---- 1. digit planes --------------------------------------------------------------------------
+// Upper bound of |a - a16| (Euclidean) from the float64 sum r2 of the squared residuals as evaluated:
+// each residual a_k - s q_k / F16 is formed with an absolute error of at most 3 u max|a| (product,
+// quotient, difference), the d squares and their sum with a relative one of (d + 2) u; a row with a
+// NaN or an infinity gives a NaN ("no bound": every candidate is kept)
+__device__ __forceinline__ double plane16_residual(double r2, double s, double amax, int d) {
+    (void)s;
+    return sqrt(r2) * (1.0 + 1e-9 + 2.3e-16 * (double)d) + sqrt((double)d) * amax * 4e-16;
+}
+
 // planes: int8 [3][rows][dpad]; scale[rows] = s; l1[rows] = sum |a_k|
 template <typename T>
 __global__ __launch_bounds__(256) void slice_rows_kernel(const T *__restrict__ A, int64_t rows,
                                                          int d, int64_t ld, int dpad,
                                                          int8_t *__restrict__ planes,
                                                          double *__restrict__ scale,
-                                                         double *__restrict__ l1) {
+                                                         double *__restrict__ l1,
+                                                         double *__restrict__ res16) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -84,9 +97,11 @@ __global__ __launch_bounds__(256) void slice_rows_kernel(const T *__restrict__ A
     if (lane == 0) { scale[row] = s; l1[row] = s1; }
     const size_t plane_stride = (size_t)rows * dpad;
     int8_t *p0 = planes + (size_t)row * dpad;
+    double r2 = 0.0;  // |a - a16|^2, a16 = s (256 D0 + D1) / F16: the row the top TWO planes stand for (2d)
     for (int k = lane; k < dpad; k += 64) {
         int q = 0;
-        if (k < d) q = (int)rint(widen(a[k]) / s * FQ);
+        const double av = k < d ? widen(a[k]) : 0.0;
+        if (k < d) q = (int)rint(av / s * FQ);
         const int d2 = ((q + 128) & 255) - 128;
         const int q1 = (q - d2) >> 8;
         const int d1 = ((q1 + 128) & 255) - 128;
@@ -94,7 +109,11 @@ __global__ __launch_bounds__(256) void slice_rows_kernel(const T *__restrict__ A
         p0[k] = (int8_t)d0;
         p0[plane_stride + k] = (int8_t)d1;
         p0[2 * plane_stride + k] = (int8_t)d2;
+        const double t = av - s * (double)q1 / F16;
+        r2 = fma(t, t, r2);
     }
+    for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off, 64);
+    if (lane == 0) res16[row] = plane16_residual(r2, s, m, d);
 }
 
 // Which k-tiles (64 features each) the seed pre-pass looks at: the nkt_used tiles in which the
@@ -190,12 +209,12 @@ struct WTables {
 };
 template <int NTHR>
 __device__ __forceinline__ void wtables_body(const double *__restrict__ tw, const double *__restrict__ l1w,
-                                             const double *__restrict__ yy_part, int M, int Mpad, int stride,
-                                             const WTables &o) {
-    __shared__ double r0[NTHR], r1[NTHR], r2[NTHR];
+                                             const double *__restrict__ yy_part, const double *__restrict__ res16,
+                                             int M, int Mpad, int stride, const WTables &o) {
+    __shared__ double r0[NTHR], r1[NTHR], r2[NTHR], r3[NTHR];
     const int t = threadIdx.x;
-    if (t < SCHED_CTR) o.sched_ctr[t] = 0u;  // bin counts / cursors / ranges of the exact stage's schedule
-    double a = 0.0, b = 0.0, c = 0.0;
+    if (t < SCHED_CTR + 2 * RF_CTR + 4) o.sched_ctr[t] = 0u;  // bin counts / cursors / ranges of the exact stage's schedule, counters of 2d
+    double a = 0.0, b = 0.0, c = 0.0, e = 0.0;
     for (int j = t; j < Mpad; j += NTHR) {
         const long js = (long)j * stride;  // j-th entry of the strided tables
         const bool in_sub = js < M;
@@ -227,14 +246,19 @@ __device__ __forceinline__ void wtables_body(const double *__restrict__ tw, cons
         o.tab32[j] = ok32 ? (float)(o.ww[j] / cs) : -INFINITY;
         o.tab32[(size_t)Mpad + j] = ok32 ? (float)(1.0 / cs) : 0.f;
         a = fmax(a, l1w[j]); b = fmax(b, tw[j]); c = fmax(c, o.ww[j]);
+        // (fmax drops a NaN: a prototype row with a NaN or an infinity must void the bound instead)
+        e = (e != e || res16[j] != res16[j]) ? NAN : fmax(e, res16[j]);
     }
-    r0[t] = a; r1[t] = b; r2[t] = c;
+    r0[t] = a; r1[t] = b; r2[t] = c; r3[t] = e;
     __syncthreads();
     for (int w = NTHR / 2; w > 0; w >>= 1) {
-        if (t < w) { r0[t] = fmax(r0[t], r0[t + w]); r1[t] = fmax(r1[t], r1[t + w]); r2[t] = fmax(r2[t], r2[t + w]); }
+        if (t < w) {
+            r0[t] = fmax(r0[t], r0[t + w]); r1[t] = fmax(r1[t], r1[t + w]); r2[t] = fmax(r2[t], r2[t + w]);
+            r3[t] = (r3[t] != r3[t] || r3[t + w] != r3[t + w]) ? NAN : fmax(r3[t], r3[t + w]);
+        }
         __syncthreads();
     }
-    if (t == 0) { o.summary[0] = r0[0]; o.summary[1] = r1[0]; o.summary[2] = r2[0]; }
+    if (t == 0) { o.summary[0] = r0[0]; o.summary[1] = r1[0]; o.summary[2] = r2[0]; o.summary[3] = r3[0]; }
     // per 256-prototype chunk: the smallest |w|^2 / c' and the smallest / largest 1 / c' of its float32
     // table entries -- the coarse integer test of the two-per-CU sweep's epilogue (a lower bound of
     // the per-pair threshold over the whole chunk).  Round u of the loop above handled chunk u, one
@@ -274,7 +298,7 @@ __device__ __forceinline__ void slice_w_row(const double *__restrict__ W, int M,
                                             const int32_t *__restrict__ kt_sel, int8_t *__restrict__ wt,
                                             int8_t *__restrict__ wt_sub, double *__restrict__ scale,
                                             double *__restrict__ l1, double *__restrict__ yy_part,
-                                            double *__restrict__ nrm0, int row, int lane) {
+                                            double *__restrict__ nrm0, double *__restrict__ res16, int row, int lane) {
     const double *a = W + (size_t)row * d;
     double m = 0.0, s1 = 0.0;
     for (int k = lane; k < d; k += 64) {
@@ -301,14 +325,18 @@ __device__ __forceinline__ void slice_w_row(const double *__restrict__ W, int M,
         if (lane == 0) yy_part[q] = p2;
     }
     long long n0 = 0;  // sum of the squared top digits (exact)
+    double r2 = 0.0;   // squared residual of the top two planes (slice_rows_kernel)
     for (int k = lane; k < dpad; k += 64) {
         int v = 0;
-        if (k < d) v = (int)rint(a[k] / s * FQ);
+        const double av = k < d ? a[k] : 0.0;
+        if (k < d) v = (int)rint(av / s * FQ);
         const int d2 = ((v + 128) & 255) - 128;
         const int v1 = (v - d2) >> 8;
         const int d1 = ((v1 + 128) & 255) - 128;
         const int d0 = (v1 - d1) >> 8;
         n0 += (long long)(d0 * d0);
+        const double tr = av - s * (double)v1 / F16;
+        r2 = fma(tr, tr, r2);
         const int kt = k >> 6, c = (k >> 4) & 3, b = k & 15;
         const size_t o = ((size_t)kt * Mpad + row) * FKT + ((c ^ ((row >> 2) & 3)) << 4) + b;
         wt[o] = (int8_t)d0;
@@ -321,8 +349,8 @@ __device__ __forceinline__ void slice_w_row(const double *__restrict__ W, int M,
             wt_sub[2 * sub_stride + oq] = (int8_t)d2;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) n0 += __shfl_xor(n0, off, 64);
-    if (lane == 0) nrm0[row] = (double)n0;
+    for (int off = 32; off > 0; off >>= 1) { n0 += __shfl_xor(n0, off, 64); r2 += __shfl_xor(r2, off, 64); }
+    if (lane == 0) { nrm0[row] = (double)n0; res16[row] = plane16_residual(r2, s, m, d); }
 }
 
 
@@ -336,14 +364,15 @@ __global__ __launch_bounds__(256) void slice_w_tiled_kernel(const double *__rest
                                                             double *__restrict__ l1,
                                                             double *__restrict__ yy_part,
                                                             double *__restrict__ nrm0,
+                                                            double *__restrict__ res16,
                                                             uint32_t *__restrict__ ticket, WTables tables) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row < M) slice_w_row(W, M, d, dpad, Mpad, stride, Msubpad, nkt_used, kt_sel, wt, wt_sub, scale, l1, yy_part,
-                             nrm0, row, lane);
+                             nrm0, res16, row, lane);
     // the per-prototype tables of the sweep need every row's scale / l1 / partial norm: the
     // workgroup that finishes last builds them (one launch less than a kernel of their own)
-    if (last_workgroup_done(ticket, gridDim.x)) wtables_body<256>(scale, l1, yy_part, M, Mpad, stride, tables);
+    if (last_workgroup_done(ticket, gridDim.x)) wtables_body<256>(scale, l1, yy_part, res16, M, Mpad, stride, tables);
 }
 
 
@@ -1614,14 +1643,15 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
 // workgroups stay together): the schedule only decides WHEN a workgroup runs, never what it writes.
 __global__ __launch_bounds__(256) void sched_fill_kernel(const uint32_t *__restrict__ ucount, int nb,
                                                          uint32_t *__restrict__ ctr,
-                                                         int32_t *__restrict__ sched) {
+                                                         int32_t *__restrict__ sched,
+                                                         const uint8_t *__restrict__ skip) {
     __shared__ uint32_t h[SCHED_BINS], base[SCHED_BINS];
     if (threadIdx.x < SCHED_BINS) h[threadIdx.x] = 0u;
     __syncthreads();
     const int b = blockIdx.x * 256 + threadIdx.x;
     int bin = -1;
     uint32_t r = 0;
-    if (b < nb) {
+    if (b < nb && !(skip && skip[b])) {  // (skip: workgroups the refinement took, section 2d)
         bin = sched_bin(ucount[b]);
         r = atomicAdd(&h[bin], 1u);
     }
@@ -2279,17 +2309,23 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
 #endif
 }
 
+#include "refine.h"
+
 // ---- launchers ----------------------------------------------------------------------------------
 struct PlaneBuf {
     int8_t *planes;
-    double *scale, *l1;
+    double *scale, *l1, *res16;
 };
 static size_t carve_planes(PlaneBuf *b, char *base, int64_t rows, int64_t d) {
     const int64_t dpad = filter_dpad(d);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o0 = take((size_t)3 * rows * dpad), o1 = take((size_t)rows * 8), o2 = take((size_t)rows * 8);
-    if (b) { b->planes = (int8_t *)(base + o0); b->scale = (double *)(base + o1); b->l1 = (double *)(base + o2); }
+    const size_t o3 = take((size_t)rows * 8);
+    if (b) {
+        b->planes = (int8_t *)(base + o0); b->scale = (double *)(base + o1); b->l1 = (double *)(base + o2);
+        b->res16 = (double *)(base + o3);
+    }
     return off;
 }
 
@@ -2299,6 +2335,7 @@ struct FilterWs {
     int8_t *wt, *wt_sub;   // k-tile-major digit planes of the prototypes / of the pre-pass subset
     double *wscale, *wl1;  // M each
     double *wn0;           // M: sum of the squared top digits of a row (section 2c)
+    double *wres16;        // M: |w - w16|, the residual of the top two digit planes (section 2d)
     double *ctab, *yypad, *ctab_sub, *yy_sub, *ictab, *yctab, *yy_part, *summary;
     float *tab32;        // 6 x Mpad float32: [yctab | ictab | yy_sub | ctab_sub 2^16 | yy | ctab 2^16] for the 2-per-CU sweep's epilogue
     float *chk32;        // Mpad / 256 x 4 float32: [min yctab, min ictab, max ictab, -] per 256-prototype chunk
@@ -2313,6 +2350,11 @@ struct FilterWs {
     int32_t *order;    // N   bucket order of the samples by seed
     float *gap;        // Mg x Mg lower bounds of the squared distances between prototypes (2c); M <= PRUNE_MAX_M
     int32_t *retry;    // nb: workgroups of the pruning form to be re-seeded
+    uint32_t *cand;    // N: per-sample candidates (positions in the workgroup's list) after the refinement (2d)
+    uint8_t *gflag;    // nb: 1 = refined, the pair kernel's; 0 = subset_exact_kernel's
+    unsigned long long *rf_ctr;  // RF_CTR counters of the refinement (behind sched_ctr, zeroed with it)
+    uint32_t *rf_qlen;           // [4]: lengths of the two class queues and the two pair queues (zeroed with it)
+    int32_t *rf_queue;           // 4 x nb: those queues
     int64_t Mg;        // its leading dimension: M rounded up to 64
     void *sort_ws;
     int64_t nb, Mpad;
@@ -2324,6 +2366,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t otk = take(256);
     const size_t ow = take((size_t)3 * Mpad * dpad), ows = take((size_t)3 * Mpad * dpad);
     const size_t osc = take((size_t)M * 8), ol1 = take((size_t)M * 8), on0 = take((size_t)M * 8);
+    const size_t ores = take((size_t)M * 8);
     const size_t o0 = take((size_t)Mpad * 8), o1 = take((size_t)Mpad * 8), o2 = take(64);
     const size_t o8 = take((size_t)Mpad * 8), o9 = take((size_t)Mpad * 8);
     const size_t o10 = take((size_t)Mpad * 8), o11 = take((size_t)Mpad * 8), o12 = take((size_t)Mpad * 8);
@@ -2333,17 +2376,24 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
     const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
-    const size_t o16 = take((size_t)nb * 4), o17 = take((size_t)SCHED_CTR * 4);
+    const size_t o16 = take((size_t)nb * 4), o17 = take((size_t)(SCHED_CTR + 2 * RF_CTR + 4) * 4);
+    const size_t o24 = take((size_t)4 * nb * 4);
+    const size_t o22 = take((size_t)N * 4), o23 = take((size_t)nb);
     const int64_t Mg = (M + 63) / 64 * 64;
     const size_t o20 = take(M <= PRUNE_MAX_M ? (size_t)Mg * Mg * 4 : 0);
     const size_t o21 = take((size_t)nb * 4);
     if (f) {
         f->retry = (int32_t *)(base + o21);
+        f->cand = (uint32_t *)(base + o22); f->gflag = (uint8_t *)(base + o23);
+        f->rf_ctr = (unsigned long long *)(base + o17 + (size_t)SCHED_CTR * 4);
+        f->rf_qlen = (uint32_t *)(base + o17 + (size_t)(SCHED_CTR + 2 * RF_CTR) * 4);
+        f->rf_queue = (int32_t *)(base + o24);
         f->gap = M <= PRUNE_MAX_M ? (float *)(base + o20) : nullptr; f->Mg = Mg;
         f->tickets = (uint32_t *)(base + otk);
         f->sched = (int32_t *)(base + o16); f->sched_ctr = (uint32_t *)(base + o17);
         f->wt = (int8_t *)(base + ow); f->wt_sub = (int8_t *)(base + ows);
         f->wscale = (double *)(base + osc); f->wl1 = (double *)(base + ol1); f->wn0 = (double *)(base + on0);
+        f->wres16 = (double *)(base + ores);
         f->ctab = (double *)(base + o0); f->yypad = (double *)(base + o1);
         f->ctab_sub = (double *)(base + o8); f->yy_sub = (double *)(base + o9);
         f->ictab = (double *)(base + o10); f->yctab = (double *)(base + o11);
@@ -2363,11 +2413,11 @@ static int launch_slice(const void *A, int dtype, int64_t rows, int64_t d, int64
     const int dpad = (int)filter_dpad(d);
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if (dtype == DBGSOM_F32)
-        hipLaunchKernelGGL(slice_rows_kernel<float>, grid, block, 0, s, (const float *)A, rows, (int)d, ld, dpad, b.planes, b.scale, b.l1);
+        hipLaunchKernelGGL(slice_rows_kernel<float>, grid, block, 0, s, (const float *)A, rows, (int)d, ld, dpad, b.planes, b.scale, b.l1, b.res16);
     else if (dtype == DBGSOM_F64)
-        hipLaunchKernelGGL(slice_rows_kernel<double>, grid, block, 0, s, (const double *)A, rows, (int)d, ld, dpad, b.planes, b.scale, b.l1);
+        hipLaunchKernelGGL(slice_rows_kernel<double>, grid, block, 0, s, (const double *)A, rows, (int)d, ld, dpad, b.planes, b.scale, b.l1, b.res16);
     else
-        hipLaunchKernelGGL(slice_rows_kernel<bf16_t>, grid, block, 0, s, (const bf16_t *)A, rows, (int)d, ld, dpad, b.planes, b.scale, b.l1);
+        hipLaunchKernelGGL(slice_rows_kernel<bf16_t>, grid, block, 0, s, (const bf16_t *)A, rows, (int)d, ld, dpad, b.planes, b.scale, b.l1, b.res16);
     return launch_status("slice_rows_kernel");
 }
 
@@ -2411,9 +2461,6 @@ struct SideStream {
     }
 };
 thread_local SideStream g_side;
-// (internal, engine.hip) distances / prototype shifts for the hinted form of the pruning bound: taken
-// by the NEXT dbgsom_bmu_filtered call of this thread that prunes, then forgotten
-thread_local const double *g_hint_dist = nullptr, *g_hint_shift = nullptr;
 }  // namespace
 
 extern "C" {
@@ -2422,10 +2469,6 @@ extern "C" {
  * dbgsom_bmu_filtered_stage_ms returns their durations for the LAST call, in milliseconds:
  * [0] slice W + tables, [1] coarse pre-pass (0 when a hint was given), [2] bucket sort,
  * [3] int8 sweep, [4] exact search on the candidates. */
-void dbgsom_filter_hint_bound(const double *dist_prev_dev, const double *shift_dev) {
-    g_hint_dist = dist_prev_dev; g_hint_shift = shift_dev;
-}
-
 int dbgsom_filter_timing(int enable) { g_timer.enabled = enable != 0; g_timer.valid = false; return DBGSOM_OK; }
 
 int dbgsom_bmu_filtered_stage_ms(double *ms5) {
@@ -2484,6 +2527,26 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                         const int32_t *order_dev, int seed_stride, int sweep_planes,
                         int round_f32, int64_t *idx_dev, double *dist_dev, void *workspace_dev,
                         size_t workspace_bytes, void *stream) {
+    FilteredCall a;
+    a.X = X_dev; a.x_dtype = x_dtype; a.N = N; a.d = d; a.ldx = ldx; a.xx = xx_dev; a.xplanes = xplanes_dev;
+    a.W = W_dev; a.M = M; a.ww = ww_dev; a.prev_idx = prev_idx_dev; a.order = order_dev;
+    a.seed_stride = seed_stride & ~DBGSOM_REFINE; a.sweep_planes = sweep_planes; a.round_f32 = round_f32;
+    a.idx = idx_dev; a.dist = dist_dev; a.ws = workspace_dev; a.ws_bytes = workspace_bytes;
+    a.stream = (hipStream_t)stream;
+    a.refine_rows = (seed_stride & DBGSOM_REFINE) ? 192 : 0;
+    return launch_bmu_filtered(a);
+}
+
+}  // extern "C"
+
+int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
+    const void *X_dev = call.X; const int x_dtype = call.x_dtype; const int64_t N = call.N, d = call.d, ldx = call.ldx;
+    const double *xx_dev = call.xx; const void *xplanes_dev = call.xplanes; const double *W_dev = call.W;
+    const int64_t M = call.M; const double *ww_dev = call.ww; const int64_t *prev_idx_dev = call.prev_idx;
+    const int32_t *order_dev = call.order; int seed_stride = call.seed_stride, sweep_planes = call.sweep_planes;
+    const int round_f32 = call.round_f32; int64_t *idx_dev = call.idx; double *dist_dev = call.dist;
+    void *workspace_dev = call.ws; const size_t workspace_bytes = call.ws_bytes; void *stream = (void *)call.stream;
+    const double *g_hint_dist = call.hint_dist, *g_hint_shift = call.hint_shift;
     // 8 wavefronts of 64 x 64 tiles (<= 128 VGPRs: four wavefronts per SIMD, two workgroups per CU)
     // or 4 of 64 x 128 (DBGSOM_SWEEP_WAVES=4; two wavefronts per SIMD).  Measured, ms per launch,
     // 4 / 8: C4 1.13 / 1.04, C3 0.88 / 0.71, C5 shard 4.96 / 4.55
@@ -2565,7 +2628,7 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     hipLaunchKernelGGL(slice_w_tiled_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, W_dev,
                        (int)M, (int)d, dpad, (int)f.Mpad, seed_stride, Msubpad, nkt_used,
                        nkt_used < nkt_full ? f.kt_sel : (const int32_t *)nullptr, f.wt,
-                       f.wt_sub, f.wscale, f.wl1, f.yy_part, f.wn0, f.tickets + 1, tables);
+                       f.wt_sub, f.wscale, f.wl1, f.yy_part, f.wn0, f.wres16, f.tickets + 1, tables);
     g_timer.mark(1, s);
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
@@ -2632,7 +2695,6 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                                prune ? 0 : 1, (const double *)nullptr, (const double *)nullptr, f.retry, rlen, 2, retry_above);
         }
     }
-    g_hint_dist = g_hint_shift = nullptr;
     // one digit product: 4-wavefront workgroups unless DBGSOM_SWEEP_SHAPE=8 (see dbgsom_sweep_shape)
     const int sweep_shape = dbgsom_sweep_shape(M, d);
     if (prune) {
@@ -2657,9 +2719,39 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
                            f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
                            (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr, f.sched_ctr);
     g_timer.mark(4, s);
+    // per-sample refinement of the lists (section 2d): workgroups it takes leave the MFMA stage's schedule
+    const int rf_rows = call.refine_rows;
+    const bool refine = rf_rows > 0;
+    if (refine) {
+        // list-length classes: a small tile for the bulk (what the caller expects the lists to be), the
+        // largest for the rest; every launch is a few workgroups per CU walking its class's queue
+        const int rows0 = rf_rows <= 32 ? 32 : (rf_rows <= 64 ? 64 : (rf_rows <= 128 ? 128 : 0));
+        const int rows1 = RefineCfg<2, 4>::MAX_CNT;
+        hipLaunchKernelGGL(class_fill_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount, (int)f.nb,
+                           rows0, rows1, f.rf_queue, f.rf_qlen, f.gflag);
+#define DBGSOM_REFINE_LAUNCH(NJ_, JT_, CLS, WGS)                                                                  \
+    hipLaunchKernelGGL((refine_i8_kernel<NJ_, JT_>), dim3((unsigned)(f.nb < (WGS) ? f.nb : (WGS))), dim3(NJ_ * 256), 0, s, \
+                       xb.planes, xb.scale, xb.res16, xx_dev, N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, ww_dev,    \
+                       f.summary, order_dev, f.ulist, (int)f.Mpad, f.ucount, f.rf_queue + (size_t)(CLS) * f.nb,      \
+                       f.rf_qlen + (CLS), f.cand, f.gflag, f.sched_ctr, f.rf_ctr, f.rf_queue + 2 * (size_t)f.nb,     \
+                       f.rf_qlen + 2, (int)f.nb)
+        if (rows0 == 32) DBGSOM_REFINE_LAUNCH(1, 1, 0, 1024);
+        else if (rows0 == 64) DBGSOM_REFINE_LAUNCH(1, 2, 0, 1024);
+        else if (rows0 == 128) DBGSOM_REFINE_LAUNCH(2, 2, 0, 512);
+        DBGSOM_REFINE_LAUNCH(2, 4, 1, 512);
+#undef DBGSOM_REFINE_LAUNCH
+#define DBGSOM_PAIR_LAUNCH(T_, UN_, Q)                                                                            \
+    hipLaunchKernelGGL((pair_exact_kernel<T_, UN_>), dim3((unsigned)(f.nb < 1536 ? f.nb : 1536)), dim3(256), 0, s,  \
+                       (const T_ *)X_dev, N, (int)d, ldx, xx_dev, W_dev, ww_dev, order_dev, f.ulist, (int)f.Mpad,    \
+                       f.ucount, f.cand, f.rf_queue + (size_t)(2 + (Q)) * f.nb, f.rf_qlen + 2 + (Q), round_f32,     \
+                       idx_dev, dist_dev)
+        if (x_dtype == DBGSOM_F32) { DBGSOM_PAIR_LAUNCH(float, 32, 0); DBGSOM_PAIR_LAUNCH(float, 64, 1); }
+        else { DBGSOM_PAIR_LAUNCH(double, 32, 0); DBGSOM_PAIR_LAUNCH(double, 64, 1); }
+#undef DBGSOM_PAIR_LAUNCH
+    }
     // (the bin counts were added up by the sweep's workgroups as they wrote their list lengths)
     hipLaunchKernelGGL(sched_fill_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount,
-                       (int)f.nb, f.sched_ctr, f.sched);
+                       (int)f.nb, f.sched_ctr, f.sched, refine ? f.gflag : (const uint8_t *)nullptr);
     // the three list-length classes write disjoint samples: they run side by side (classes 1 and 2
     // on a second stream forked from the caller's), so that the tail of one launch -- a few long
     // lists on a mostly idle chip -- overlaps the others
@@ -2670,7 +2762,8 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
         const char *e = getenv("DBGSOM_EXACT_FORK");
         return e ? atoi(e) : 1;
     }();
-    const bool fork = fork_env != 0 && side.ready();
+    // (with the refinement the class kernels are nearly empty: a fork and two joins cost more than they run)
+    const bool fork = fork_env != 0 && !refine && side.ready();
     hipStream_t s2 = fork ? side.stream : s, s3 = fork ? side.stream2 : s;
     if (fork) {
         DBGSOM_HIP_CHECK(hipEventRecord(side.forked, s));
@@ -2736,6 +2829,8 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
     return launch_status("filtered bmu kernels");
 }
 
+extern "C" {
+
 #if SWEEP_EXPERIMENT & (256 | 512 | 1024)
 size_t dbgsom_debug_ulist_offset(int64_t N, int64_t d, int64_t M) {
     FilterWs f;
@@ -2760,6 +2855,16 @@ int dbgsom_bmu_filtered_counts(const void *workspace_dev, int64_t N, int64_t d, 
     DBGSOM_REQUIRE(n_counts == f.nb, "n_counts must be ceil(N / 128)");
     DBGSOM_HIP_CHECK(hipMemcpyAsync(counts_host, f.ucount, (size_t)f.nb * 4, hipMemcpyDeviceToHost,
                                     (hipStream_t)stream));
+    DBGSOM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return DBGSOM_OK;
+}
+
+int dbgsom_bmu_filtered_refine_counts(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
+                                      uint64_t *out4, void *stream) {
+    DBGSOM_REQUIRE(workspace_dev && out4, "null pointer");
+    FilterWs f;
+    carve_filter(&f, (char *)const_cast<void *>(workspace_dev), N, d, M);
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(out4, f.rf_ctr, (size_t)RF_CTR * 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
     DBGSOM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return DBGSOM_OK;
 }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DBGSOM_ABI_VERSION 2
+#define DBGSOM_ABI_VERSION 3
 
 /* sample storage types (the reference accepts float64 and float32 input: SomVQ.py:121-124) */
 #define DBGSOM_F32 0
@@ -64,6 +64,12 @@ extern "C" {
  * whose pruned lists come out longer than max(96, M / 8) -- their seeds were poor -- are seeded again
  * against every prototype and pruned again (two more short launches) */
 #define DBGSOM_PRUNE_RETRY 0x800
+/* per-SAMPLE refinement in front of the exact stage: the four int8 digit products of the top two digit
+ * planes over each workgroup's candidate list leave every sample the few prototypes a certified bound
+ * cannot separate (<= 4, else its whole list); the float64 chain then runs on those (sample, prototype)
+ * pairs alone, on the vector ALU, with the gathered rows streamed once.  Workgroups whose lists do not
+ * fit the refinement's tile (192 entries) go through the matrix-core stage as without the flag. */
+#define DBGSOM_REFINE 0x1000
 
 /* prototype-count limit of the accumulate step (per-block LDS histogram) */
 #define DBGSOM_MAX_PROTOTYPES 16000
@@ -178,6 +184,12 @@ int dbgsom_bmu_filtered_counts(const void *workspace_dev, int64_t N, int64_t d, 
  * valid once the caller has synchronised the stream */
 int dbgsom_bmu_filtered_counts_async(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
                                      uint32_t *counts_host, int64_t n_counts, void *stream);
+
+/* diagnostics of the per-sample refinement (DBGSOM_REFINE) of the last filtered call:
+ * out4 = [(sample, prototype) pairs evaluated exactly, workgroups refined, workgroups left to the
+ * matrix-core stage, 0]; synchronises the stream */
+int dbgsom_bmu_filtered_refine_counts(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
+                                      uint64_t *out4, void *stream);
 
 /* ---- post-fit consumers of the BMU step as device reductions (N-sized arrays stay in HBM) ---- */
 
@@ -372,6 +384,8 @@ int dbgsom_ctx_subset_create(dbgsom_ctx *ctx, int64_t neuron, dbgsom_ctx **child
 int dbgsom_ctx_epoch_info(dbgsom_ctx *ctx, double *info8);
 /* candidate-list length per 128-sample workgroup of the last filtered search (n = ceil(N/128)) */
 int dbgsom_ctx_filter_counts(dbgsom_ctx *ctx, uint32_t *counts_host, int64_t n);
+/* dbgsom_bmu_filtered_refine_counts of the context's last filtered search */
+int dbgsom_ctx_refine_counts(dbgsom_ctx *ctx, uint64_t *out4);
 /* ms8 = [bmu, accumulate, smooth, slice W + tables, seed pre-pass, bucket sort, candidate sweep,
  *        exact search on candidates] of the last epoch (option "timing" = 1) */
 int dbgsom_ctx_phase_ms(dbgsom_ctx *ctx, double *ms8);
