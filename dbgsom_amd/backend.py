@@ -285,7 +285,10 @@ class HipBackend(HotPathBackend):
     seed_stride = property(lambda self: self._get("seed_stride"),
                            lambda self, v: self._set("seed_stride", v))
     # per-sample refinement in front of the exact stage of the filtered search (filter.hip 2d)
-    refine = property(lambda self: bool(self._get("refine")), lambda self, v: self._set("refine", bool(v)))
+    # 0 / False = off, 1 / True = on, 2 = by measurement (the default): the engine times the exact stage of
+    # the first epochs of a map size with and without it and keeps the faster form
+    refine = property(lambda self: self._get("refine"), lambda self, v: self._set("refine", int(v)))
+    refined = property(lambda self: bool(self._get("refined")))   # what the last filtered search ran
     planes_cached = property(lambda self: bool(self._get("planes_cached")))
     padded_features = property(lambda self: self._get("padded_features"))
 
@@ -587,11 +590,11 @@ class HipBackend(HotPathBackend):
         return out
 
     def refine_counts(self):
-        """[(sample, prototype) pairs evaluated exactly, workgroups refined, workgroups left to the
-        matrix-core stage] of the last filtered search."""
+        """[(sample, prototype) pairs evaluated exactly, 128-sample workgroups refined, samples whose
+        candidates overflowed the four slots] of the last filtered search."""
         out = np.zeros(4, dtype=np.uint64)
         self._call("dbgsom_ctx_refine_counts", self._ctx, out.ctypes.data)
-        return [int(v) for v in out[:3]]
+        return [int(v) for v in out]
 
     def traffic(self):
         """PCIe traffic of the prototypes since the context was created / last released."""

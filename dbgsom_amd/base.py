@@ -306,7 +306,12 @@ class BaseSom(BaseEstimator):
         need_assign = self.growth_criterion == "entropy"
         n_classes = 0
         if need_assign:
-            if not isinstance(data, DeviceSamples):   # a device subset brought its labels along
+            if isinstance(data, DeviceSamples):
+                # A device subset brought its PARENT's label codes along; this fit has re-coded y
+                # (np.unique in fit), and the subset's rows are in the stable bucket order the
+                # caller cut y_sub in (y[winners == j]): attach the child's own codes.
+                engine.set_labels(y)
+            else:
                 lo, hi = (0, data.shape[0]) if self._local_input() else self._shard
                 engine.set_labels(y[lo:hi])
             n_classes = int(self.classes_.shape[0])

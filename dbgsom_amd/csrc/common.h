@@ -129,6 +129,11 @@ struct FilteredCall {
     const double *hint_dist = nullptr, *hint_shift = nullptr;
     // per-sample refinement of the candidate lists (2d): 0 = off, else the longest list it should take
     int refine_rows = 0;
+    // the stored rows when they are not what X points to (bfloat16 storage behind a float32 copy): the
+    // pair kernel of the refinement streams these
+    const void *X_store = nullptr;
+    int store_dtype = -1;
+    int64_t ld_store = 0;
 };
 int launch_bmu_filtered(const FilteredCall &call);
 size_t smooth_workspace_bytes(int64_t M, int64_t d);

@@ -235,7 +235,15 @@ struct dbgsom_ctx {
     int seed_stride = 0;
     int timing = 0;
     int use_graph = 0;
-    int refine = 1;  // per-sample refinement in front of the exact stage (filter.hip 2d)
+    // per-sample refinement in front of the exact stage (filter.hip 2d): 0 = off, 1 = on, 2 = by measurement
+    // (the exact stage of the first training epochs of a map size is timed with and without it -- HIP
+    // events on the stream -- and the faster form kept; re-measured when the lists change by a quarter)
+    int refine = 2;
+    double rf_ms[2] = {NAN, NAN};   // exact stage without / with the refinement
+    int64_t rf_M = -1;
+    double rf_mean_ref = NAN;
+    int rf_measuring = -1;          // the form the running call is timing (-1: none)
+    bool last_refined = false;
     int64_t filter_min_query_rows = 32768;
     int64_t max_mean_candidates = 320;
     // samples
@@ -478,8 +486,28 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     // the tile of the refinement's first list-length class: what the lists were last time, with some room
     // (longer lists go to its largest tile, beyond that to the matrix-core stage)
     int rf_rows = 64;
-    if (c->last_mean == c->last_mean && c->last_filter_M == M) rf_rows = (int)(c->last_mean * 1.25 + 8.0);
-    call.refine_rows = c->refine ? rf_rows : 0;
+    const bool mean_known = c->last_mean == c->last_mean && c->last_filter_M == M;
+    if (mean_known) rf_rows = (int)(c->last_mean * 1.25 + 8.0);
+    bool use_refine = c->refine == 1;
+    if (c->rf_measuring >= 0 && !c->timing) (void)dbgsom_filter_timing(0);  // (a measurement nobody read)
+    c->rf_measuring = -1;
+    if (c->refine == 2 && mean_known) {
+        if (c->rf_M != M || !(fabs(c->last_mean - c->rf_mean_ref) <= 0.25 * c->rf_mean_ref)) {
+            c->rf_M = M; c->rf_mean_ref = c->last_mean; c->rf_ms[0] = c->rf_ms[1] = NAN;
+        }
+        // prior (what has not been measured is not tried blind): the refinement reads two digit planes and the
+        // rows once more whatever the lists are -- short lists, few features or a few workgroups never pay;
+        // lists beyond twice its largest tile stay the matrix-core stage's anyway
+        const bool eligible = c->last_mean >= 24.0 && c->last_mean <= 400.0 && s.dp >= 256 && s.N >= 65536;
+        if (!eligible) use_refine = false;
+        else if (may_probe && c->rf_ms[0] != c->rf_ms[0]) { use_refine = false; c->rf_measuring = 0; }
+        else if (may_probe && c->rf_ms[1] != c->rf_ms[1]) { use_refine = true; c->rf_measuring = 1; }
+        else use_refine = c->rf_ms[1] < c->rf_ms[0];   // (false while either is unknown)
+    }
+    if (c->rf_measuring >= 0 && !c->timing) TRY(dbgsom_filter_timing(1));
+    call.refine_rows = use_refine ? rf_rows : 0;
+    c->last_refined = use_refine;
+    if (s.dtype == DBGSOM_BF16) { call.X_store = s.X; call.store_dtype = DBGSOM_BF16; call.ld_store = s.dp; }
     TRY(launch_bmu_filtered(call));
     c->last_filter_M = M; c->last_filter_N = s.N; c->last_filter_d = s.dp; c->last_filter_ws = ws.p;
     return DBGSOM_OK;
@@ -744,8 +772,13 @@ int smooth_and_fetch(dbgsom_ctx *c, int64_t M, double sigma, int layout, int fla
     if (dist_host) DBGSOM_HIP_CHECK(hipMemcpyAsync(dist_host, c->dist.p, (size_t)s.N * 8, hipMemcpyDeviceToHost, c->stream));
     TRY(sync(c));
     c->ev_valid = c->timing != 0;
-    if (c->timing && c->last_filtered) {
+    if ((c->timing || c->rf_measuring >= 0) && c->last_filtered) {
         c->filter_ms_valid = dbgsom_bmu_filtered_stage_ms(c->filter_ms) == DBGSOM_OK;
+        if (c->rf_measuring >= 0) {
+            if (c->filter_ms_valid) c->rf_ms[c->rf_measuring] = c->filter_ms[4];
+            if (!c->timing) { (void)dbgsom_filter_timing(0); c->filter_ms_valid = false; }
+            c->rf_measuring = -1;
+        }
     } else {
         c->filter_ms_valid = false;
     }
@@ -803,7 +836,12 @@ int dbgsom_ctx_create(int device, dbgsom_ctx **out) {
     c->device = device;
     const char *e = getenv("DBGSOM_SWEEP_PLANES");  // diagnostic: fixes the digit planes of every context
     if (e) { const int v = atoi(e); if (v >= 0 && v <= 4) c->sweep_planes = v; }
-    hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // (highest priority: the side streams of the filtered search -- a few long chains off the critical
+    //  path -- must not starve the short dependent kernels of this one)
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    hipError_t err = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high);
+    if (err != hipSuccess) { (void)hipGetLastError(); err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); }
     if (err != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(err));
         delete c;
@@ -849,7 +887,9 @@ int dbgsom_ctx_set_option(dbgsom_ctx *c, const char *name, int64_t v) {
     } else if (!strcmp(name, "graph")) {
         c->use_graph = v != 0;
     } else if (!strcmp(name, "refine")) {
-        c->refine = v != 0;
+        DBGSOM_REQUIRE(v >= 0 && v <= 2, "refine must be 0 (off), 1 (on) or 2 (by measurement)");
+        c->refine = (int)v;
+        c->rf_ms[0] = c->rf_ms[1] = NAN;
     } else if (!strcmp(name, "filter_min_query_rows")) {
         DBGSOM_REQUIRE(v >= 0, "filter_min_query_rows must be >= 0");
         c->filter_min_query_rows = v;
@@ -872,6 +912,7 @@ int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
     else if (!strcmp(name, "timing")) *v = c->timing;
     else if (!strcmp(name, "graph")) *v = c->use_graph;
     else if (!strcmp(name, "refine")) *v = c->refine;
+    else if (!strcmp(name, "refined")) *v = c->last_refined ? 1 : 0;
     else if (!strcmp(name, "filter_min_query_rows")) *v = c->filter_min_query_rows;
     else if (!strcmp(name, "max_mean_candidates")) *v = c->max_mean_candidates;
     else if (!strcmp(name, "n_samples")) *v = c->xs.dtype < 0 ? 0 : c->xs.N;

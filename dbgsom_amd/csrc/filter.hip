@@ -57,8 +57,10 @@ constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
 // plane rows are padded to whole k-tiles, at least two of them (the sweep's ring runs three tiles
 // ahead and keeps three chunk tables)
 inline int64_t filter_dpad(int64_t d) {
-    const int64_t p = (d + FKT - 1) / FKT * FKT;
-    return p < 2 * FKT ? 2 * FKT : p;
+    // (whole 128-byte lines per row: with 64-byte pitches every second row starts in the middle of a line
+    //  and a pass over gathered rows fetches 1.5 x the plane -- measured on prune_mark_kernel at d = 784)
+    const int64_t p = (d + 2 * FKT - 1) / (2 * FKT) * (2 * FKT);
+    return p;
 }
 
 // ---- 1. digit planes --------------------------------------------------------------------------
@@ -439,6 +441,12 @@ typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
 __device__ __forceinline__ void fdma16(const void *src, void *lds_dst) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_dst, 16, 0, 0);
+}
+
+// the same for bytes that are read once (streamed sample rows): non-temporal, so that they do not push the
+// prototype tiles every workgroup shares out of the L2
+__device__ __forceinline__ void fdma16_nt(const void *src, void *lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_dst, 16, 0, 2);
 }
 
 // the same with an immediate offset, which the instruction adds to BOTH the global and the LDS address
@@ -2350,11 +2358,14 @@ struct FilterWs {
     int32_t *order;    // N   bucket order of the samples by seed
     float *gap;        // Mg x Mg lower bounds of the squared distances between prototypes (2c); M <= PRUNE_MAX_M
     int32_t *retry;    // nb: workgroups of the pruning form to be re-seeded
-    uint32_t *cand;    // N: per-sample candidates (positions in the workgroup's list) after the refinement (2d)
-    uint8_t *gflag;    // nb: 1 = refined, the pair kernel's; 0 = subset_exact_kernel's
+    unsigned long long *cand;  // N: per-sample candidates (four prototype ids) after the refinement (2d)
+    int64_t *rbest;    // N: the refinement's best prototype per sample (bucket key of the pair kernel)
+    int32_t *order2;   // N: the samples bucketed by it
+    int32_t *ovf;      // 2 N: (sample, workgroup) of the samples whose candidates overflowed
+    uint8_t *gflag;    // nb: 1 = refined (pair kernel); 0 = subset_exact_kernel's
     unsigned long long *rf_ctr;  // RF_CTR counters of the refinement (behind sched_ctr, zeroed with it)
-    uint32_t *rf_qlen;           // [4]: lengths of the two class queues and the two pair queues (zeroed with it)
-    int32_t *rf_queue;           // 4 x nb: those queues
+    uint32_t *rf_qlen;           // [4]: lengths of the two class queues, of the overflow list, - (zeroed with it)
+    int32_t *rf_queue;           // 2 x nb: the class queues
     int64_t Mg;        // its leading dimension: M rounded up to 64
     void *sort_ws;
     int64_t nb, Mpad;
@@ -2377,14 +2388,16 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
     const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
     const size_t o16 = take((size_t)nb * 4), o17 = take((size_t)(SCHED_CTR + 2 * RF_CTR + 4) * 4);
-    const size_t o24 = take((size_t)4 * nb * 4);
-    const size_t o22 = take((size_t)N * 4), o23 = take((size_t)nb);
+    const size_t o24 = take((size_t)2 * nb * 4);
+    const size_t o25 = take((size_t)N * 8), o26 = take((size_t)N * 4), o27 = take((size_t)N * 8);
+    const size_t o22 = take((size_t)N * 8), o23 = take((size_t)nb);
     const int64_t Mg = (M + 63) / 64 * 64;
     const size_t o20 = take(M <= PRUNE_MAX_M ? (size_t)Mg * Mg * 4 : 0);
     const size_t o21 = take((size_t)nb * 4);
     if (f) {
         f->retry = (int32_t *)(base + o21);
-        f->cand = (uint32_t *)(base + o22); f->gflag = (uint8_t *)(base + o23);
+        f->cand = (unsigned long long *)(base + o22); f->gflag = (uint8_t *)(base + o23);
+        f->rbest = (int64_t *)(base + o25); f->order2 = (int32_t *)(base + o26); f->ovf = (int32_t *)(base + o27);
         f->rf_ctr = (unsigned long long *)(base + o17 + (size_t)SCHED_CTR * 4);
         f->rf_qlen = (uint32_t *)(base + o17 + (size_t)(SCHED_CTR + 2 * RF_CTR) * 4);
         f->rf_queue = (int32_t *)(base + o24);
@@ -2443,7 +2456,7 @@ thread_local StageTimer g_timer;
 // created the work simply stays on the caller's stream)
 struct SideStream {
     hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t forked = nullptr, joined = nullptr, joined2 = nullptr;
+    hipEvent_t forked = nullptr, joined = nullptr, joined2 = nullptr, mid = nullptr;
     int state = 0;  // 0 untried, 1 ready, -1 unavailable
     int device = -1;
     bool ready() {
@@ -2451,11 +2464,17 @@ struct SideStream {
         if (hipGetDevice(&dev) != hipSuccess) return false;
         if (state == 0) {
             device = dev;
-            state = (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
-                     hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking) == hipSuccess &&
+            // (lowest priority: what runs here is off the critical path -- a few long chains beside the
+            //  caller's stream -- and must not starve the short dependent kernels there: at equal priority the
+            //  bucket sort between the refinement and the pair kernel took 0.5 ms instead of 0.06)
+            int prio_low = 0, prio_high = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+            state = (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_low) == hipSuccess &&
+                     hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio_low) == hipSuccess &&
                      hipEventCreateWithFlags(&forked, hipEventDisableTiming) == hipSuccess &&
                      hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&joined2, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
+                     hipEventCreateWithFlags(&joined2, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&mid, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
         }
         return state == 1 && dev == device;  // a thread that moved to another device: no fork
     }
@@ -2722,39 +2741,9 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
     // per-sample refinement of the lists (section 2d): workgroups it takes leave the MFMA stage's schedule
     const int rf_rows = call.refine_rows;
     const bool refine = rf_rows > 0;
-    if (refine) {
-        // list-length classes: a small tile for the bulk (what the caller expects the lists to be), the
-        // largest for the rest; every launch is a few workgroups per CU walking its class's queue
-        const int rows0 = rf_rows <= 32 ? 32 : (rf_rows <= 64 ? 64 : (rf_rows <= 128 ? 128 : 0));
-        const int rows1 = RefineCfg<2, 4>::MAX_CNT;
-        hipLaunchKernelGGL(class_fill_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount, (int)f.nb,
-                           rows0, rows1, f.rf_queue, f.rf_qlen, f.gflag);
-#define DBGSOM_REFINE_LAUNCH(NJ_, JT_, CLS, WGS)                                                                  \
-    hipLaunchKernelGGL((refine_i8_kernel<NJ_, JT_>), dim3((unsigned)(f.nb < (WGS) ? f.nb : (WGS))), dim3(NJ_ * 256), 0, s, \
-                       xb.planes, xb.scale, xb.res16, xx_dev, N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, ww_dev,    \
-                       f.summary, order_dev, f.ulist, (int)f.Mpad, f.ucount, f.rf_queue + (size_t)(CLS) * f.nb,      \
-                       f.rf_qlen + (CLS), f.cand, f.gflag, f.sched_ctr, f.rf_ctr, f.rf_queue + 2 * (size_t)f.nb,     \
-                       f.rf_qlen + 2, (int)f.nb)
-        if (rows0 == 32) DBGSOM_REFINE_LAUNCH(1, 1, 0, 1024);
-        else if (rows0 == 64) DBGSOM_REFINE_LAUNCH(1, 2, 0, 1024);
-        else if (rows0 == 128) DBGSOM_REFINE_LAUNCH(2, 2, 0, 512);
-        DBGSOM_REFINE_LAUNCH(2, 4, 1, 512);
-#undef DBGSOM_REFINE_LAUNCH
-#define DBGSOM_PAIR_LAUNCH(T_, UN_, Q)                                                                            \
-    hipLaunchKernelGGL((pair_exact_kernel<T_, UN_>), dim3((unsigned)(f.nb < 1536 ? f.nb : 1536)), dim3(256), 0, s,  \
-                       (const T_ *)X_dev, N, (int)d, ldx, xx_dev, W_dev, ww_dev, order_dev, f.ulist, (int)f.Mpad,    \
-                       f.ucount, f.cand, f.rf_queue + (size_t)(2 + (Q)) * f.nb, f.rf_qlen + 2 + (Q), round_f32,     \
-                       idx_dev, dist_dev)
-        if (x_dtype == DBGSOM_F32) { DBGSOM_PAIR_LAUNCH(float, 32, 0); DBGSOM_PAIR_LAUNCH(float, 64, 1); }
-        else { DBGSOM_PAIR_LAUNCH(double, 32, 0); DBGSOM_PAIR_LAUNCH(double, 64, 1); }
-#undef DBGSOM_PAIR_LAUNCH
-    }
-    // (the bin counts were added up by the sweep's workgroups as they wrote their list lengths)
-    hipLaunchKernelGGL(sched_fill_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount,
-                       (int)f.nb, f.sched_ctr, f.sched, refine ? f.gflag : (const uint8_t *)nullptr);
-    // the three list-length classes write disjoint samples: they run side by side (classes 1 and 2
-    // on a second stream forked from the caller's), so that the tail of one launch -- a few long
-    // lists on a mostly idle chip -- overlaps the others
+    // the three list-length classes of the matrix-core stage write disjoint samples: they run side by side
+    // (classes 1 and 2 on a second stream forked from the caller's), so that the tail of one launch -- a few
+    // long lists on a mostly idle chip -- overlaps the others
     SideStream &side = g_side;
     // (measured also for few buckets, where the fork and join cost ~20 us of bubbles: C2 0.168 -> 0.123
     // ms for the stage, a 125 k-row shard of C4 0.303 -> 0.265; DBGSOM_EXACT_FORK=0 runs them in a row)
@@ -2762,13 +2751,71 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         const char *e = getenv("DBGSOM_EXACT_FORK");
         return e ? atoi(e) : 1;
     }();
-    // (with the refinement the class kernels are nearly empty: a fork and two joins cost more than they run)
-    const bool fork = fork_env != 0 && !refine && side.ready();
+    const bool fork = fork_env != 0 && side.ready();
     hipStream_t s2 = fork ? side.stream : s, s3 = fork ? side.stream2 : s;
+    // With the refinement the matrix-core stage only has the workgroups the refinement does not take (lists
+    // beyond its tiles: a few long chains on a mostly idle chip): all of it on the second stream, beside the
+    // refinement and the pair kernel on the caller's; the samples whose candidates overflowed on the third.
+    hipStream_t s_mfma = refine ? s2 : s;
+    const int rows0 = rf_rows <= 32 ? 32 : (rf_rows <= 64 ? 64 : (rf_rows <= 128 ? 128 : 0));
+    if (refine)
+        // list-length classes of the refinement: a small tile for the bulk (what the caller expects the
+        // lists to be), the largest for the rest; workgroups in neither stay the matrix-core stage's
+        hipLaunchKernelGGL(class_fill_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount, (int)f.nb,
+                           rows0, RF_SEGS * (int)RefineCfg<2, 4>::MAX_CNT, f.rf_queue, f.rf_qlen, f.gflag, f.sched_ctr, order_dev,
+                           prev_idx_dev, N, (int)M, f.cand, f.rbest);
+    else
+        // (the bin counts were added up by the sweep's workgroups as they wrote their list lengths)
+        hipLaunchKernelGGL(sched_fill_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount,
+                           (int)f.nb, f.sched_ctr, f.sched, (const uint8_t *)nullptr);
     if (fork) {
         DBGSOM_HIP_CHECK(hipEventRecord(side.forked, s));
         DBGSOM_HIP_CHECK(hipStreamWaitEvent(s2, side.forked, 0));
         DBGSOM_HIP_CHECK(hipStreamWaitEvent(s3, side.forked, 0));
+    }
+    if (refine) {
+        hipLaunchKernelGGL(sched_fill_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s_mfma, f.ucount,
+                           (int)f.nb, f.sched_ctr, f.sched, (const uint8_t *)f.gflag);
+        if (fork) {  // (classes 2 and 1 run on the third stream: behind the schedule)
+            DBGSOM_HIP_CHECK(hipEventRecord(side.mid, s_mfma));
+            DBGSOM_HIP_CHECK(hipStreamWaitEvent(s3, side.mid, 0));
+        }
+        // every launch is a few workgroups per CU walking its class's queue
+#define DBGSOM_REFINE_LAUNCH(NJ_, JT_, CLS, WGS)                                                                  \
+    hipLaunchKernelGGL((refine_i8_kernel<NJ_, JT_>), dim3((unsigned)(f.nb < (WGS) ? f.nb : (WGS))), dim3(NJ_ * 256), 0, s, \
+                       xb.planes, xb.scale, xb.res16, xx_dev, N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, ww_dev,    \
+                       f.summary, order_dev, f.ulist, (int)f.Mpad, f.ucount, f.rf_queue + (size_t)(CLS) * f.nb,      \
+                       f.rf_qlen + (CLS), f.cand, f.rbest, f.rf_ctr, f.ovf, f.rf_qlen + 2)
+        if (rows0 == 32) DBGSOM_REFINE_LAUNCH(1, 1, 0, 1024);
+        else if (rows0 == 64) DBGSOM_REFINE_LAUNCH(1, 2, 0, 1024);
+        else if (rows0 == 128) DBGSOM_REFINE_LAUNCH(2, 2, 0, 512);
+        DBGSOM_REFINE_LAUNCH(2, 4, 1, 512);
+#undef DBGSOM_REFINE_LAUNCH
+        // the samples by their refined best prototype: a workgroup of the pair kernel then shares its candidates
+        const int rc = launch_bucket_sort(f.rbest, N, M, f.order2, f.sort_ws, s);
+        if (rc != DBGSOM_OK) return rc;
+        // (bfloat16-resident samples: the pair kernel reads the stored rows -- half the bytes of the widened
+        //  copy the matrix kernels use, the same values)
+        const unsigned pgrid = (unsigned)((N + PS - 1) / PS);
+        if (call.X_store && call.store_dtype == DBGSOM_BF16 && x_dtype == DBGSOM_F32)
+            hipLaunchKernelGGL((pair_exact_kernel<bf16_t, 32, 128>), dim3(pgrid), dim3(256), 0, s, (const bf16_t *)call.X_store, N,
+                               (int)d, call.ld_store, xx_dev, W_dev, ww_dev, f.order2, f.cand, round_f32, idx_dev, dist_dev, f.rf_ctr);
+        else if (x_dtype == DBGSOM_F32)
+            hipLaunchKernelGGL((pair_exact_kernel<float, 16, 256>), dim3(pgrid), dim3(256), 0, s, (const float *)X_dev, N,
+                               (int)d, ldx, xx_dev, W_dev, ww_dev, f.order2, f.cand, round_f32, idx_dev, dist_dev, f.rf_ctr);
+        else
+            hipLaunchKernelGGL((pair_exact_kernel<double, 16, 256>), dim3(pgrid), dim3(256), 0, s, (const double *)X_dev, N,
+                               (int)d, ldx, xx_dev, W_dev, ww_dev, f.order2, f.cand, round_f32, idx_dev, dist_dev, f.rf_ctr);
+        // (the samples whose candidates overflowed: behind the pair kernel, not beside it -- its uncoalesced
+        //  row walks slowed the sort and the pair kernel by more than it takes)
+        if (x_dtype == DBGSOM_F32)
+            hipLaunchKernelGGL((overflow_exact_kernel<float>), dim3(512), dim3(256), 0, s, (const float *)X_dev, (int)d, ldx,
+                               xx_dev, W_dev, ww_dev, f.ulist, (int)f.Mpad, f.ucount, f.ovf, f.rf_qlen + 2, round_f32,
+                               idx_dev, dist_dev);
+        else
+            hipLaunchKernelGGL((overflow_exact_kernel<double>), dim3(512), dim3(256), 0, s, (const double *)X_dev, (int)d, ldx,
+                               xx_dev, W_dev, ww_dev, f.ulist, (int)f.Mpad, f.ucount, f.ovf, f.rf_qlen + 2, round_f32,
+                               idx_dev, dist_dev);
     }
 #define DBGSOM_SUBSET_W(JTL, NWV_, STREAM)                                                        \
     do {                                                                                          \
@@ -2803,7 +2850,8 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         const char *e = getenv("DBGSOM_EXACT_SPLIT");
         return e ? atoi(e) : -1;
     }();
-    const bool exact_split = split_env >= 0 ? split_env != 0 : f.nb <= 1024;
+    // (with the refinement: what is left to this stage is a few workgroups)
+    const bool exact_split = split_env >= 0 ? split_env != 0 : (refine || f.nb <= 1024);
     // (two digits: class 3, then classes 2 and 1)
 #define DBGSOM_SUBSET(JTL, STREAM)                                                                \
     do {                                                                                          \
@@ -2811,8 +2859,8 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         if (w_ == 8) DBGSOM_SUBSET_W(JTL, 8, STREAM);                                             \
         else DBGSOM_SUBSET_W(JTL, 4, STREAM);                                                     \
     } while (0)
-    DBGSOM_SUBSET(3, s);
-    DBGSOM_SUBSET(2, s2);
+    DBGSOM_SUBSET(3, s_mfma);
+    DBGSOM_SUBSET(2, refine ? s3 : s2);
     DBGSOM_SUBSET(1, s3);
 #undef DBGSOM_SUBSET
 #undef DBGSOM_SUBSET_W

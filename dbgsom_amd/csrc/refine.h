@@ -31,9 +31,10 @@
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
 constexpr int RF_C = 4;               // candidate slots per sample
+constexpr int RF_SEGS = 2;            // tile-sized segments a candidate list may have in the refinement
 constexpr int RF_MAX_PAIRS = 512;     // pairs per 128-sample workgroup of the pair kernel (two per lane)
-constexpr int RF_MAX_UNION = 64;      // distinct prototypes among them (rows of its W tile); gflag 1: <= 32, 2: <= 64
-constexpr uint32_t RF_NONE = 0xffffffffu, RF_ALL = 0xfefefefeu;
+constexpr int RF_HASH = 512;          // slots of its table of distinct candidates
+constexpr unsigned long long RF_NONE = 0xffffffffffffffffull;  // four empty slots (prototype ids are < 0xffff)
 
 template <int NJ, int JT>
 struct RefineCfg {
@@ -51,24 +52,24 @@ struct RefineCfg {
     static constexpr int W_OPS = (ROWS / 8) / NW;
     static constexpr int OPS = X_OPS + W_OPS;
     static_assert(16 % NW == 0 && (ROWS / 8) % NW == 0, "whole DMA instructions per wavefront");
-    static constexpr int MAX_CNT = ROWS < 0xfd ? ROWS : 0xfd;  // list positions are bytes (0xfe, 0xff: markers)
+    static constexpr int MAX_CNT = ROWS;
 };
 
 template <int NJ, int JT>
-__global__ __launch_bounds__(NJ * 256, 2) void refine_i8_kernel(
+__global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx, const double *__restrict__ xres,
     const double *__restrict__ xx, int64_t N, int d, int dpad, const int8_t *__restrict__ wplanes, int w_rows,
     const double *__restrict__ tw, const double *__restrict__ ww, const double *__restrict__ summary,
     const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
     const uint32_t *__restrict__ ucount, const int32_t *__restrict__ queue, const uint32_t *__restrict__ queue_len,
-    uint32_t *__restrict__ cand, uint8_t *__restrict__ gflag, uint32_t *__restrict__ sched_ctr,
-    unsigned long long *__restrict__ rf_ctr, int32_t *__restrict__ pair_queue, uint32_t *__restrict__ pair_len, int nb) {
+    unsigned long long *__restrict__ cand, int64_t *__restrict__ rbest, unsigned long long *__restrict__ rf_ctr,
+    int32_t *__restrict__ ovf, uint32_t *__restrict__ ovf_len) {
     // (one launch per list-length class, a few workgroups per CU walking the class's queue of 128-sample
-    //  workgroups -- class_fill_kernel; pair_queue / pair_len: [2] queues of the pair kernel, by union size)
+    //  workgroups -- class_fill_kernel)
     using C = RefineCfg<NJ, JT>;
     __shared__ __attribute__((aligned(16))) char smem[C::BYTES];
     double *tab_y = reinterpret_cast<double *>(smem + C::OFF_TAB), *tab_c = tab_y + C::ROWS;
-    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + C::OFF_MISC);  // [0..7] union bits, [8] pairs, [9] all
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + C::OFF_MISC);  // [8] pairs of this workgroup
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave & 3, wj = wave >> 2;
@@ -78,9 +79,23 @@ __global__ __launch_bounds__(NJ * 256, 2) void refine_i8_kernel(
     if (entry != (int)blockIdx.x) __syncthreads();  // the previous workgroup's tables are done with
     const int group = queue[entry];
     const int64_t p0 = (int64_t)group * 128;
-    const int cnt = __builtin_amdgcn_readfirstlane((int)ucount[group]);  // 1 <= cnt <= MAX_CNT (class_fill_kernel)
-    const uint16_t *list = ulist + (size_t)group * ulist_stride;
-    if (tid < 10) misc[tid] = 0u;
+    const int cnt_all = __builtin_amdgcn_readfirstlane((int)ucount[group]);  // 1 <= cnt_all <= RF_SEGS ROWS (class_fill_kernel)
+    const uint16_t *list_all = ulist + (size_t)group * ulist_stride;
+    // A list longer than the tile (a workgroup whose samples come from two clusters: 4 % of the C5 shard's) is
+    // taken in segments of ROWS entries, each a pass over the planes of its own; a sample's candidates of
+    // a segment are chosen against the SEGMENT's minimum (a superset), merged by the sample's thread and
+    // filtered against the minimum of the whole list at the end.
+    const int nseg = (cnt_all + C::ROWS - 1) / C::ROWS;
+    float g_m = INFINITY, g_v[RF_SEGS * RF_C];
+    int g_best = (int)list_all[0], g_n = 0, g_id[RF_SEGS * RF_C];
+    bool g_ovf = false;
+#pragma unroll
+    for (int e = 0; e < RF_SEGS * RF_C; ++e) { g_v[e] = 0.f; g_id[e] = 0xffff; }
+    for (int seg = 0; seg < nseg; ++seg) {
+    if (seg) __syncthreads();  // the previous segment's v_ij have been read
+    const uint16_t *list = list_all + seg * C::ROWS;
+    const int cnt = min(C::ROWS, cnt_all - seg * C::ROWS);
+    if (tid < 10 && seg == 0) misc[tid] = 0u;
     for (int l = tid; l < C::ROWS; l += C::NW * 64) {
         const int j = (int)list[l < cnt ? l : cnt - 1];
         tab_y[l] = ww[j];
@@ -180,82 +195,159 @@ __global__ __launch_bounds__(NJ * 256, 2) void refine_i8_kernel(
         int64_t p = p0 + col;
         p = p < N ? p : N - 1;
         const double s_i = sx[order[p]];
+        // (the lane's first list row, made opaque here: left visible, the 48 JT table / output addresses are
+        //  hoisted out of the queue loop, kept across the matrix loop and spilled)
+        int lb = wj * 32 * JT + 4 * lh;
+        asm volatile("" : "+v"(lb));
+        const double *ty = tab_y + lb, *tc = tab_c + lb;
+        float *vcol = vm + lb * 128 + col;
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             if (jt < njt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int l = wj * 32 * JT + jt * 32 + 8 * (r >> 2) + (r & 3) + 4 * lh;
+                    const int lo = jt * 32 + 8 * (r >> 2) + (r & 3);
                     const double T = ((double)acc[jt][0][r] * 256.0 + (double)acc[jt][1][r]) * 256.0 + (double)acc[jt][2][r];
-                    vm[l * 128 + col] = (float)(tab_y[l] - s_i * (tab_c[l] * T));
+                    vcol[lo * 128] = (float)(ty[lo] - s_i * (tc[lo] * T));
+                    // (four values at a time: left to itself the scheduler converts all 16 JT accumulators first)
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
     }
     __syncthreads();
-    if (tid < 128) {
-        const int64_t p = p0 + tid;
-        if (p < N) {
-            const int64_t i = order[p];
-            const double yy_max = summary[2], rw = summary[3], xv = xx[i], rx = xres[i];
+    {
+        // selection: SP threads per sample, each over a contiguous part of the list (parts in list order, so
+        // that candidates come out ascending); scratch behind the v_ij matrix, inside the ring's bytes
+        constexpr int SP = C::NW * 64 / 128 > 4 ? 4 : C::NW * 64 / 128;
+        static_assert(C::MAIN - C::VM >= 4 * 128 * 24, "selection scratch behind the v_ij matrix");
+        float *pm = reinterpret_cast<float *>(smem + C::MAIN - 4 * 128 * 24);
+        int *plm = reinterpret_cast<int *>(pm + 4 * 128), *pn = plm + 4 * 128;
+        uint32_t *ppos = reinterpret_cast<uint32_t *>(pn + 4 * 128);
+        unsigned long long *psl = reinterpret_cast<unsigned long long *>(ppos + 4 * 128);
+        const int part = tid >> 7, sidx = tid & 127;
+        const bool act = part < SP && p0 + sidx < N;
+        const int l0 = part * cnt / SP, l1 = (part + 1) * cnt / SP;
+        if (act) {
+            float m = INFINITY;
+            int lm = l0;
+#pragma unroll 4
+            for (int l = l0; l < l1; ++l) {  // (a NaN never becomes the minimum)
+                const float v = vm[l * 128 + sidx];
+                if (v < m) { m = v; lm = l; }
+            }
+            pm[part * 128 + sidx] = m;
+            plm[part * 128 + sidx] = lm;
+        }
+        __syncthreads();
+        double eps2 = 0.0;
+        if (act) {
+            const int64_t isamp = order[p0 + sidx];
+            const double yy_max = summary[2], rw = summary[3], xv = xx[isamp], rx = xres[isamp];
             const double xn = sqrt(xv) * (1.0 + 1e-9), wn = sqrt(yy_max) * (1.0 + 1e-9);
             const double rounding = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xv + yy_max);
-            const double eps2 = 2.0 * (2.0 * (rx * (wn + rw) + xn * rw) * (1.0 + 1e-9) + rounding);
+            eps2 = 2.0 * (2.0 * (rx * (wn + rw) + xn * rw) * (1.0 + 1e-9) + rounding);
             float m = INFINITY;
-            for (int l = 0; l < cnt; ++l) m = fminf(m, vm[l * 128 + tid]);  // (fminf passes over a NaN)
+#pragma unroll
+            for (int q = 0; q < SP; ++q) m = fminf(m, pm[q * 128 + sidx]);  // (fminf passes over a NaN)
             // v <= min + 2 eps, with both sides' rounding to float32 on the safe side; a NaN anywhere keeps
             const double thr = (double)m + eps2 + 2.4e-7 * (fabs((double)m) + eps2);
             int n = 0;
-            uint32_t slots = RF_NONE;
-            for (int l = 0; l < cnt; ++l) {
-                if (!((double)vm[l * 128 + tid] > thr)) {
-                    if (n < RF_C) slots = (slots & ~(0xffu << (8 * n))) | ((uint32_t)l << (8 * n));
+            unsigned long long slots = RF_NONE;
+            uint32_t pos = 0u;
+#pragma unroll 4
+            for (int l = l0; l < l1; ++l) {
+                if (!((double)vm[l * 128 + sidx] > thr)) {
+                    if (n < RF_C) {
+                        slots = (slots & ~(0xffffull << (16 * n))) | ((unsigned long long)list[l] << (16 * n));
+                        pos |= (uint32_t)l << (8 * n);
+                    }
                     ++n;
                 }
             }
-            if (n > RF_C) {
-                slots = RF_ALL;
-                n = cnt;
-                misc[9] = 1u;
-            } else {
+            psl[part * 128 + sidx] = slots;
+            ppos[part * 128 + sidx] = pos;
+            pn[part * 128 + sidx] = n;
+        }
+        __syncthreads();
+        if (act && part == 0) {  // this segment's candidates (ascending) behind those of the earlier ones
+            int n = 0;
+#pragma unroll
+            for (int q = 0; q < SP; ++q) {
+                const float mq = pm[q * 128 + sidx];
+                if (mq < g_m) { g_m = mq; g_best = (int)list[plm[q * 128 + sidx]]; }
+                const int nq = pn[q * 128 + sidx];
+                const unsigned long long sq = psl[q * 128 + sidx];
+                const uint32_t pq = ppos[q * 128 + sidx];
 #pragma unroll
                 for (int e = 0; e < RF_C; ++e) {
-                    const uint32_t l = (slots >> (8 * e)) & 0xffu;
-                    if (e < n) atomicOr(&misc[l >> 5], 1u << (l & 31));
+                    if (e < nq && n + e < RF_C) {
+                        const float v = vm[((pq >> (8 * e)) & 0xffu) * 128 + sidx];
+                        const int id = (int)((sq >> (16 * e)) & 0xffffull);
+#pragma unroll
+                        for (int z = 0; z < RF_SEGS * RF_C; ++z)  // (no dynamic register indexing)
+                            if (z == g_n + n + e) { g_v[z] = v; g_id[z] = id; }
+                    }
                 }
+                n += nq;
             }
-            cand[p] = slots;
-            atomicAdd(&misc[8], (uint32_t)n);
+            if (n > RF_C) g_ovf = true;
+            g_n += n < RF_C ? n : RF_C;
         }
+    }
+    }  // (segments)
+    if (tid < 128 && p0 + tid < N) {
+        // the candidates of all segments against the minimum of the whole list
+        const int64_t isamp = order[p0 + tid];
+        const double yy_max = summary[2], rw = summary[3], xv = xx[isamp], rx = xres[isamp];
+        const double xn = sqrt(xv) * (1.0 + 1e-9), wn = sqrt(yy_max) * (1.0 + 1e-9);
+        const double rounding = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xv + yy_max);
+        const double eps2 = 2.0 * (2.0 * (rx * (wn + rw) + xn * rw) * (1.0 + 1e-9) + rounding);
+        const double thr = (double)g_m + eps2 + 2.4e-7 * (fabs((double)g_m) + eps2);
+        int n = 0;
+        unsigned long long slots = RF_NONE;
+#pragma unroll
+        for (int z = 0; z < RF_SEGS * RF_C; ++z) {
+            if (z < g_n && !((double)g_v[z] > thr)) {
+                if (n < RF_C) slots = (slots & ~(0xffffull << (16 * n))) | ((unsigned long long)g_id[z] << (16 * n));
+                ++n;
+            }
+        }
+        if (n > RF_C || g_ovf) {  // too many to keep apart: the whole list, exactly, by overflow_exact_kernel
+            slots = RF_NONE;
+            atomicAdd(rf_ctr + 2, 1ull);
+            const uint32_t k = atomicAdd(ovf_len, 1u);
+            ovf[2 * (size_t)k] = (int32_t)isamp;
+            ovf[2 * (size_t)k + 1] = group;
+            n = 0;
+        }
+        cand[isamp] = slots;
+        rbest[isamp] = (int64_t)g_best;  // bucket key of the pair kernel: any prototype does, the likely winner is best
+        atomicAdd(&misc[8], (uint32_t)n);
     }
     __syncthreads();
     if (tid == 0) {
-        int uni = 0;
-        if (misc[9]) uni = cnt;
-        else
-            for (int w = 0; w < 8; ++w) uni += __popc(misc[w]);
-        const bool ok = misc[8] <= (uint32_t)RF_MAX_PAIRS && uni <= RF_MAX_UNION;
-        gflag[group] = ok ? 1 : 0;
-        if (ok) {
-            atomicSub(&sched_ctr[sched_bin((uint32_t)cnt)], 1u);  // not a workgroup of the MFMA stage after all
-            atomicAdd(rf_ctr + 0, (unsigned long long)misc[8]);
-            atomicAdd(rf_ctr + 1, 1ull);
-            const int u = uni <= 32 ? 0 : 1;
-            pair_queue[(size_t)u * nb + atomicAdd(&pair_len[u], 1u)] = group;
-        } else {
-            atomicAdd(rf_ctr + 2, 1ull);
-        }
+        atomicAdd(rf_ctr + 0, (unsigned long long)misc[8]);
+        atomicAdd(rf_ctr + 1, 1ull);
     }
     }  // (queue)
 }
 
 // which refinement class (tile) takes a 128-sample workgroup: queue 0 = lists of 1 .. rows0 entries, queue 1 =
-// longer ones up to the largest tile's; longer still (or empty): nobody's, gflag stays 0
+// longer ones up to the largest tile's (gflag 1, out of the matrix-core stage's bin counts); longer still (or
+// empty): gflag 0, the matrix-core stage's, and its samples get a bucket key (their seed) and no candidates
+// for the pair kernel
 __global__ __launch_bounds__(256) void class_fill_kernel(const uint32_t *__restrict__ ucount, int nb, int rows0,
                                                          int rows1, int32_t *__restrict__ queue,
-                                                         uint32_t *__restrict__ queue_len, uint8_t *__restrict__ gflag) {
-    __shared__ uint32_t h[2], base[2];
-    if (threadIdx.x < 2) h[threadIdx.x] = 0u;
+                                                         uint32_t *__restrict__ queue_len, uint8_t *__restrict__ gflag,
+                                                         uint32_t *__restrict__ sched_ctr,
+                                                         const int32_t *__restrict__ order,
+                                                         const int64_t *__restrict__ prev, int64_t N, int M,
+                                                         unsigned long long *__restrict__ cand,
+                                                         int64_t *__restrict__ rbest) {
+    __shared__ uint32_t h[3], base[2];
+    __shared__ int skipped[256];
+    if (threadIdx.x < 3) h[threadIdx.x] = 0u;
     __syncthreads();
     const int b = blockIdx.x * 256 + threadIdx.x;
     int cls = -1;
@@ -263,211 +355,257 @@ __global__ __launch_bounds__(256) void class_fill_kernel(const uint32_t *__restr
     if (b < nb) {
         const int cnt = (int)ucount[b];
         cls = cnt < 1 ? -1 : (cnt <= rows0 ? 0 : (cnt <= rows1 ? 1 : -1));
-        gflag[b] = 0;
-        if (cls >= 0) r = atomicAdd(&h[cls], 1u);
+        gflag[b] = cls >= 0 ? 1 : 0;
+        if (cls >= 0) {
+            r = atomicAdd(&h[cls], 1u);
+            atomicSub(&sched_ctr[sched_bin((uint32_t)cnt)], 1u);  // not a workgroup of the matrix-core stage after all
+        } else {
+            skipped[atomicAdd(&h[2], 1u)] = b;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 2) base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&queue_len[threadIdx.x], h[threadIdx.x]) : 0u;
+    const int nskip = (int)h[2];
+    for (int e = threadIdx.x; e < nskip * 128; e += 256) {
+        const int64_t p = (int64_t)skipped[e >> 7] * 128 + (e & 127);
+        if (p < N) {
+            const int64_t i = order[p], q = prev[i];
+            cand[i] = RF_NONE;
+            rbest[i] = (q >= 0 && q < M) ? q : 0;
+        }
+    }
     __syncthreads();
     if (cls >= 0) queue[(size_t)cls * nb + base[cls] + r] = b;
 }
 
 // ---- exact chain on the (sample, candidate) pairs ------------------------------------------------------
-// One workgroup per refined 128-sample workgroup; lane = pair (two rounds of 256), X tile (128 gathered
-// rows x KT) and W tile (the <= UN distinct candidates x KT) in a 4-stage LDS-DMA ring, three tiles in
-// flight (the kernel is bound by the gathered rows it streams, once: bytes in flight are what counts).
-// UN = 32 / 64: one queue each (refine_i8_kernel sorts the workgroups by the number of distinct candidates),
-// a few workgroups per CU walk it.  K = 1.
-template <typename XT, int UN>
+// The samples arrive bucketed by their refined best prototype (order2), so the PS = 64 samples of a workgroup
+// share a handful of candidates: lane = pair (<= 256), X tile (64 gathered rows x 256 bytes) and W tile (UN
+// distinct candidates x the same features) in a 3-stage LDS-DMA ring, two tiles in flight.  The kernel is
+// bound by the gathered rows it streams, once -- and by how they are asked for: 64-byte pieces of a row
+// (one 16-feature tile at a time, as subset_exact_kernel reads them) reached 4.4 TB/s, every piece a
+// different DRAM page; a piece here is 256 contiguous bytes.  More than UN distinct candidates (rare):
+// further passes over the rows, UN candidates each.  K = 1.
+constexpr int PS = 64;           // samples per workgroup
+constexpr int PX_PAIRS = PS * RF_C;
+template <typename XT, int UN, int PIECE>
 __global__ __launch_bounds__(256, 2) void pair_exact_kernel(
     const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
-    const double *__restrict__ W, const double *__restrict__ ww, const int32_t *__restrict__ order,
-    const uint16_t *__restrict__ ulist, int ulist_stride, const uint32_t *__restrict__ ucount,
-    const uint32_t *__restrict__ cand, const int32_t *__restrict__ queue, const uint32_t *__restrict__ queue_len,
-    int round_f32, int64_t *__restrict__ idx_out, double *__restrict__ dist_out) {
-    constexpr int PX_STAGES = sizeof(XT) == 4 ? 4 : 3;  // (float64 rows: three stages, two tiles in flight)
-    constexpr int XROW = KT * (int)sizeof(XT), XCH = XROW / 16, XD = 128 * XROW / 1024 / 4;
-    constexpr int WD = UN / 32;  // W tile: UN rows x 128 B = UN / 8 instructions, UN / 32 per wavefront
-    constexpr int S_XT = 128 * XROW, S_WT = UN * KT * 8, S_STAGE = S_XT + S_WT;
-    static_assert(PX_STAGES * S_STAGE >= RF_MAX_PAIRS * 8, "the pairs' results take the ring's place");
-    // ONE LDS object: with several, the compiler tags every access with the object's alias scope and then
+    const double *__restrict__ W, const double *__restrict__ ww, const int32_t *__restrict__ order2,
+    const unsigned long long *__restrict__ cand, int round_f32, int64_t *__restrict__ idx_out,
+    double *__restrict__ dist_out, unsigned long long *__restrict__ rf_ctr) {
+    constexpr int STAGES = 3;
+    constexpr int ES = (int)sizeof(XT);
+    constexpr int KP = PIECE / ES;              // features per tile: 64 (float32, bfloat16 in 128-byte pieces) / 32 (float64)
+    constexpr int XCH = PIECE / 16;             // 16-byte chunks of an X piece
+    constexpr int XSH = PIECE == 256 ? 0 : 1;   // rows per 256 bytes of the X tile, as a shift (swizzle below)
+    constexpr int WROW = KP * 8, WCH = WROW / 16;  // W piece: 512 / 256 bytes, 32 / 16 chunks
+    constexpr int S_XT = PS * PIECE, S_WT = UN * WROW, S_STAGE = S_XT + S_WT;
+    constexpr int XD = S_XT / 1024 / 4, WDI = S_WT / 1024;  // DMA instructions: X per wavefront; W in all
+    static_assert(PIECE == 256 || PIECE == 128, "X pieces of one or two cache lines");
+    static_assert(WDI % 4 == 0, "whole W instructions per wavefront");
+    constexpr int WD = WDI / 4;
+    static_assert(STAGES * S_STAGE >= PX_PAIRS * 8, "the pairs' results take the ring's place");
+    // ONE LDS object: with several, the compiler tags every access with its object's alias scope and then
     // answers each LDS read that may alias an LDS-DMA in flight with s_waitcnt vmcnt(0) -- no prefetch left
-    constexpr int RING = PX_STAGES * S_STAGE;
-    __shared__ __attribute__((aligned(16))) char smem[RING + UN * 4 + 130 * 4 + 8 * 4 + 2 * RF_MAX_PAIRS];
-    int *rows = reinterpret_cast<int *>(smem + RING);
-    int *off_s = rows + UN, *wtot = off_s + 128;
-    uint32_t *bits = reinterpret_cast<uint32_t *>(wtot + 2);
-    uint8_t *psamp = reinterpret_cast<uint8_t *>(bits + 8), *pslot = psamp + RF_MAX_PAIRS;
+    constexpr int RING = STAGES * S_STAGE;
+    constexpr int O_TAB = RING, O_ROWS = O_TAB + RF_HASH * 4, O_DENSE = O_ROWS + PX_PAIRS * 4,
+                  O_PSLOT = O_DENSE + RF_HASH * 2, O_OFF = O_PSLOT + PX_PAIRS * 2, O_MISC = O_OFF + PS * 4,
+                  O_PSAMP = O_MISC + 16 * 4, BYTES = O_PSAMP + PX_PAIRS;
+    __shared__ __attribute__((aligned(16))) char smem[BYTES];
+    uint32_t *table = reinterpret_cast<uint32_t *>(smem + O_TAB);
+    int *rows = reinterpret_cast<int *>(smem + O_ROWS);
+    uint16_t *dense = reinterpret_cast<uint16_t *>(smem + O_DENSE), *pslot = reinterpret_cast<uint16_t *>(smem + O_PSLOT);
+    int *off_s = reinterpret_cast<int *>(smem + O_OFF), *misc = reinterpret_cast<int *>(smem + O_MISC);
+    uint8_t *psamp = reinterpret_cast<uint8_t *>(smem + O_PSAMP);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qn = (int)*queue_len;
-    for (int entry = blockIdx.x; entry < qn; entry += gridDim.x) {
-    if (entry != (int)blockIdx.x) __syncthreads();  // the previous workgroup's results have been read
-    const int group = queue[entry];
-    const int64_t p0 = (int64_t)group * 128;
-    const int cnt = (int)ucount[group];
-    const uint16_t *list = ulist + (size_t)group * ulist_stride;
+    const int64_t p0 = (int64_t)blockIdx.x * PS;
 
     // ---- pairs and the distinct candidates --------------------------------------------------------
-    if (tid < 8) bits[tid] = 0u;
-    uint32_t slots = RF_NONE;
+    for (int h = tid; h < RF_HASH; h += 256) table[h] = 0xffffffffu;
+    unsigned long long slots = RF_NONE;
+    int64_t isamp = -1;
     int n = 0;
-    if (tid < 128 && p0 + tid < N) {
-        slots = cand[p0 + tid];
-        if (slots == RF_ALL) n = cnt;
-        else
+    if (tid < PS) {  // (wavefront 0)
+        if (p0 + tid < N) {
+            isamp = order2[p0 + tid];
+            slots = cand[isamp];
 #pragma unroll
-            for (int e = 0; e < RF_C; ++e) n += ((slots >> (8 * e)) & 0xffu) != 0xffu;
-    }
-    __syncthreads();
-    if (tid < 128) {
-        if (slots == RF_ALL) {
-            for (int l = 0; l < cnt; ++l) atomicOr(&bits[l >> 5], 1u << (l & 31));
-        } else {
-#pragma unroll
-            for (int e = 0; e < RF_C; ++e) {
-                const uint32_t l = (slots >> (8 * e)) & 0xffu;
-                if (l != 0xffu) atomicOr(&bits[l >> 5], 1u << (l & 31));
-            }
+            for (int e = 0; e < RF_C; ++e) n += ((slots >> (16 * e)) & 0xffffull) != 0xffffull;
         }
-        // exclusive scan of n over the 128 sample threads
-        int pre = n;
+        int pre = n;  // exclusive scan of n over the sample threads
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int v = __shfl_up(pre, o, 64);
             if (lane >= o) pre += v;
         }
-        if (lane == 63) wtot[tid >> 6] = pre;
+        if (lane == 63) misc[0] = pre;
         off_s[tid] = pre - n;
     }
     __syncthreads();
-    if (tid >= 64 && tid < 128) off_s[tid] += wtot[0];
-    const int npairs = wtot[0] + wtot[1];
-    __syncthreads();
-    auto slot_of = [&](uint32_t l) {
-        int s = 0;
-        for (uint32_t w = 0; w < (l >> 5); ++w) s += __popc(bits[w]);
-        return s + __popc(bits[l >> 5] & ((1u << (l & 31)) - 1u));
-    };
-    if (tid < cnt && ((bits[tid >> 5] >> (tid & 31)) & 1u)) rows[slot_of((uint32_t)tid)] = (int)list[tid];
-    if (tid < 128 && n > 0) {
+    const int npairs = misc[0];
+    if (npairs == 0) return;  // (samples of workgroups the refinement did not take: the matrix-core stage's)
+    if (tid < PS) {
         int q = off_s[tid];
-        if (slots == RF_ALL) {
-            for (int l = 0; l < cnt; ++l, ++q) { psamp[q] = (uint8_t)tid; pslot[q] = (uint8_t)l; }  // (every bit set: slot = l)
-        } else {
 #pragma unroll
-            for (int e = 0; e < RF_C; ++e) {
-                const uint32_t l = (slots >> (8 * e)) & 0xffu;
-                if (l != 0xffu) { psamp[q] = (uint8_t)tid; pslot[q] = (uint8_t)slot_of(l); ++q; }
+        for (int e = 0; e < RF_C; ++e) {
+            const uint32_t id = (uint32_t)((slots >> (16 * e)) & 0xffffull);
+            if (id != 0xffffu) {
+                uint32_t h = (id * 2654435761u) >> 23;  // 9 bits
+                for (;;) {
+                    const uint32_t old = atomicCAS(&table[h], 0xffffffffu, id);
+                    if (old == 0xffffffffu || old == id) break;
+                    h = (h + 1) & (RF_HASH - 1);
+                }
+                psamp[q] = (uint8_t)tid;
+                pslot[q] = (uint16_t)h;  // (the table slot for now)
+                ++q;
             }
         }
     }
     __syncthreads();
-    int nun = 0;
+    {   // dense numbering of the occupied table slots: 2 per thread, scan over the 256 threads
+        const bool o0 = table[2 * tid] != 0xffffffffu, o1 = table[2 * tid + 1] != 0xffffffffu;
+        int pre = (int)o0 + (int)o1;
+        const int mine = pre;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) nun += __popc(bits[w]);
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(pre, o, 64);
+            if (lane >= o) pre += v;
+        }
+        if (lane == 63) misc[4 + wave] = pre;
+        __syncthreads();
+        int basew = 0;
+        for (int w = 0; w < wave; ++w) basew += misc[4 + w];
+        const int first = basew + pre - mine;
+        if (o0) { dense[2 * tid] = (uint16_t)first; rows[first] = (int)table[2 * tid]; }
+        if (o1) { dense[2 * tid + 1] = (uint16_t)(first + (int)o0); rows[first + (int)o0] = (int)table[2 * tid + 1]; }
+    }
+    __syncthreads();
+    const int nun = misc[4] + misc[5] + misc[6] + misc[7];
+    if (tid < npairs) pslot[tid] = dense[pslot[tid]];
+    __syncthreads();
 
-    // ---- DMA sources (X as subset_exact_kernel; W: 8 rows per instruction) -----------------------------
+    // ---- DMA sources: an X instruction = 4 rows x 256 bytes, a W instruction = 1024 / WROW rows ----------
+    // LDS chunk cp of row r holds the row's chunk cp ^ swz(r), swz = the row's number among the rows that share
+    // its banks: a lane reads its pair's row chunk by chunk, the lanes of a 16-lane read group hit 16 different
+    // bank quads (or the same address)
     const XT *xsrc[XD];
+    int xchunk[XD];
 #pragma unroll
     for (int u = 0; u < XD; ++u) {
         const int L = 64 * (XD * wave + u) + lane;
         const int r = L / XCH, cp = L % XCH;
-        const int c = cp ^ ((r >> 1) & (XCH - 1));
+        xchunk[u] = cp ^ ((r >> XSH) & (XCH - 1));
         int64_t p = p0 + r;
         p = p < N ? p : N - 1;
-        xsrc[u] = X + (int64_t)order[p] * ldx + c * (16 / (int)sizeof(XT));
+        xsrc[u] = X + (int64_t)order2[p] * ldx;
     }
-    const double *wsrc[WD];
+    const int nkt = (d + KP - 1) / KP;
+    const int npass = (nun + UN - 1) / UN;
+    if (tid == 0) atomicAdd(rf_ctr + 3, (unsigned long long)nun);  // (diagnostics: distinct candidates met)
+    double acc = 0.0;
+    const bool mine = tid < npairs;
+    const int prow = mine ? (int)psamp[tid] : 0, psl = mine ? (int)pslot[tid] : -1;
+    const int xo = prow * PIECE, xsw = (prow >> XSH) & (XCH - 1);
+    for (int pass = 0; pass < npass; ++pass) {
+        if (pass) __syncthreads();  // the previous pass's last tiles have been read
+        const double *wsrc[WD];
+        int wchunk[WD];
 #pragma unroll
-    for (int u = 0; u < WD; ++u) {
-        const int wr = 8 * (WD * wave + u) + (lane >> 3), wcp = lane & 7;
-        const int wc = (wcp ^ ((wr >> 1) & 7)) * 2;
-        wsrc[u] = W + (int64_t)rows[wr < nun ? wr : (nun > 0 ? nun - 1 : 0)] * d + wc;
-    }
-    const int nkt = d / KT;
-    int i_kt = 0, i_stage = 0;
-    auto issue = [&]() {
-        char *stage = smem + i_stage;
-        const int k0 = i_kt * KT;
+        for (int u = 0; u < WD; ++u) {
+            const int L = 64 * (WD * wave + u) + lane;
+            const int wr = L / WCH, wcp = L % WCH;
+            wchunk[u] = wcp ^ (wr & 15);
+            const int sl = pass * UN + wr;
+            wsrc[u] = W + (int64_t)rows[sl < nun ? sl : nun - 1] * d;
+        }
+        const int sl = psl - pass * UN;
+        const bool live = psl >= 0 && sl >= 0 && sl < UN;
+        const int wo = S_XT + (live ? sl : 0) * WROW, wsw = (live ? sl : 0) & 15;
+        int i_kt = 0, i_stage = 0;
+        auto issue = [&]() {
+            char *stage = smem + i_stage;
+            const int k0 = i_kt * KP;
+            // (a chunk behind the row's end -- the last tile of a row whose length is no multiple of the
+            //  tile -- is never read: any address inside the row will do)
 #pragma unroll
-        for (int u = 0; u < XD; ++u) fdma16(xsrc[u] + k0, stage + 1024 * (XD * wave + u));
-#pragma unroll
-        for (int u = 0; u < WD; ++u) fdma16(wsrc[u] + k0, stage + S_XT + 1024 * (WD * wave + u));
-        i_stage = (i_stage == (PX_STAGES - 1) * S_STAGE) ? 0 : i_stage + S_STAGE;
-        ++i_kt;
-    };
-    // this lane's (at most two) pairs
-    int xo[2], xs_[2], wo[2], ws_[2];
-    bool live[2];
-    double acc[2] = {0.0, 0.0};
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int q = tid + 256 * pp;
-        live[pp] = q < npairs;
-        const int r = live[pp] ? (int)psamp[q] : 0, sl = live[pp] ? (int)pslot[q] : 0;
-        xo[pp] = r * XROW; xs_[pp] = (r >> 1) & (XCH - 1);
-        wo[pp] = S_XT + sl * 128; ws_[pp] = (sl >> 1) & 7;
-    }
-    const bool second = npairs > 256;  // (workgroup-uniform)
-    issue();
-    if (nkt > 1) issue();
-    if (PX_STAGES == 4 && nkt > 2) issue();
-    int r_stage = 0;
-    for (int t = 0; t < nkt; ++t) {
-        // the wavefront's own DMAs of tile t have landed (PX_STAGES - 2 younger tiles may stay in flight),
-        // the barrier covers everybody's
-        if (PX_STAGES == 4 && t + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (XD + WD)) : "memory");
-        else if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XD + WD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + PX_STAGES - 1 < nkt) issue();  // into the stage tile t - 1 was read from
-        const char *stage = smem + r_stage;
-        r_stage = (r_stage == (PX_STAGES - 1) * S_STAGE) ? 0 : r_stage + S_STAGE;
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            if (pp == 1 && !second) break;
-            double xv[KT], wv[KT];
-            if constexpr (sizeof(XT) == 4) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const v4f_t f = *reinterpret_cast<const v4f_t *>(stage + xo[pp] + ((c ^ xs_[pp]) << 4));
-                    xv[4 * c] = (double)f.x; xv[4 * c + 1] = (double)f.y; xv[4 * c + 2] = (double)f.z; xv[4 * c + 3] = (double)f.w;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const d2_t f = *reinterpret_cast<const d2_t *>(stage + xo[pp] + ((c ^ xs_[pp]) << 4));
-                    xv[2 * c] = f.x; xv[2 * c + 1] = f.y;
-                }
+            for (int u = 0; u < XD; ++u) {
+                const int k = k0 + xchunk[u] * (16 / ES);
+                fdma16(xsrc[u] + (k < d ? k : 0), stage + 1024 * (XD * wave + u));
             }
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const d2_t f = *reinterpret_cast<const d2_t *>(stage + wo[pp] + ((c ^ ws_[pp]) << 4));
-                wv[2 * c] = f.x; wv[2 * c + 1] = f.y;
+            for (int u = 0; u < WD; ++u) {
+                const int k = k0 + wchunk[u] * 2;
+                fdma16(wsrc[u] + (k < d ? k : 0), stage + S_XT + 1024 * (WD * wave + u));
             }
-            // (the prototype is the first factor, as the A operand of the matrix instruction)
+            i_stage = (i_stage == (STAGES - 1) * S_STAGE) ? 0 : i_stage + S_STAGE;
+            ++i_kt;
+        };
+        issue();
+        if (nkt > 1) issue();
+        int r_stage = 0;
+        for (int t = 0; t < nkt; ++t) {
+            // the wavefront's own DMAs of tile t have landed (one younger tile may stay in flight), the barrier
+            // covers everybody's
+            if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XD + WD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 2 < nkt) issue();  // into the stage tile t - 1 was read from
+            const char *stage = smem + r_stage;
+            r_stage = (r_stage == (STAGES - 1) * S_STAGE) ? 0 : r_stage + S_STAGE;
+            if (live) {
+                const int nsub = min(KP, d - t * KP) / KT;  // 16-feature blocks of this tile (d % 16 == 0)
+                for (int sb = 0; sb < nsub; ++sb) {
+                    double xv[KT], wv[KT];
+                    if constexpr (ES == 4) {
 #pragma unroll
-            for (int k = 0; k < KT; ++k) acc[pp] = fma(wv[k], xv[k], acc[pp]);
+                        for (int c = 0; c < 4; ++c) {
+                            const v4f_t f = *reinterpret_cast<const v4f_t *>(stage + xo + (((4 * sb + c) ^ xsw) << 4));
+                            xv[4 * c] = (double)f.x; xv[4 * c + 1] = (double)f.y; xv[4 * c + 2] = (double)f.z; xv[4 * c + 3] = (double)f.w;
+                        }
+                    } else if constexpr (ES == 2) {  // bfloat16: the upper half of a float32, exactly
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const v4i_t f = *reinterpret_cast<const v4i_t *>(stage + xo + (((2 * sb + c) ^ xsw) << 4));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                xv[8 * c + 2 * e] = (double)__uint_as_float(((uint32_t)f[e]) << 16);
+                                xv[8 * c + 2 * e + 1] = (double)__uint_as_float(((uint32_t)f[e]) & 0xffff0000u);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const d2_t f = *reinterpret_cast<const d2_t *>(stage + xo + (((8 * sb + c) ^ xsw) << 4));
+                            xv[2 * c] = f.x; xv[2 * c + 1] = f.y;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const d2_t f = *reinterpret_cast<const d2_t *>(stage + wo + (((8 * sb + c) ^ wsw) << 4));
+                        wv[2 * c] = f.x; wv[2 * c + 1] = f.y;
+                    }
+                    // (the prototype is the first factor, as the A operand of the matrix instruction)
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) acc = fma(wv[k], xv[k], acc);
+                }
+            }
         }
     }
     __syncthreads();  // the ring is done with: the pairs' results take its place
     double *pv = reinterpret_cast<double *>(smem);
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int q = tid + 256 * pp;
-        if (q < npairs) {
-            const int r = (int)psamp[q];
-            const int j = rows[(int)pslot[q]];
-            const double xi = xx[order[p0 + r]];
-            double rv = (xi + (-2.0 * acc[pp])) + ww[j];
-            if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
-            pv[q] = rv;
-        }
+    if (mine) {
+        const int j = rows[psl];
+        const double xi = xx[order2[p0 + prow]];
+        double rv = (xi + (-2.0 * acc)) + ww[j];
+        if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
+        pv[tid] = rv;
     }
     __syncthreads();
-    if (tid < 128 && p0 + tid < N) {
+    if (tid < PS && n > 0) {
         double bv = INFINITY;
         int bj = 0x7fffffff;
         const int q0 = off_s[tid];
@@ -476,11 +614,62 @@ __global__ __launch_bounds__(256, 2) void pair_exact_kernel(
             const int j = rows[(int)pslot[q0 + e]];
             if (v < bv) { bv = v; bj = j; }  // (Best<1>::push: the pairs of a sample come with ascending index)
         }
-        const int64_t i = order[p0 + tid];
         double dv = sqrt(bv);
         if (round_f32) dv = (double)(float)dv;
-        idx_out[i] = (bj == 0x7fffffff) ? (int64_t)-1 : (int64_t)bj;
-        dist_out[i] = dv;
+        idx_out[isamp] = (bj == 0x7fffffff) ? (int64_t)-1 : (int64_t)bj;
+        dist_out[isamp] = dv;
     }
-    }  // (queue)
+}
+
+// ---- samples whose candidates did not fit RF_C slots: their workgroup's whole list, exactly -------------
+// (rare -- duplicated prototypes, a collapsed map, rows the bound says nothing about; one 256-thread
+// workgroup per sample, a few of them walking the queue; thread = list entry, the chain in plain loops)
+template <typename XT>
+__global__ __launch_bounds__(256) void overflow_exact_kernel(
+    const XT *__restrict__ X, int d, int64_t ldx, const double *__restrict__ xx, const double *__restrict__ W,
+    const double *__restrict__ ww, const uint16_t *__restrict__ ulist, int ulist_stride,
+    const uint32_t *__restrict__ ucount, const int32_t *__restrict__ ovf, const uint32_t *__restrict__ ovf_len,
+    int round_f32, int64_t *__restrict__ idx_out, double *__restrict__ dist_out) {
+    __shared__ double sv[256];
+    __shared__ int sj[256];
+    const int tid = threadIdx.x;
+    const uint32_t qn = *ovf_len;
+    for (uint32_t e = blockIdx.x; e < qn; e += gridDim.x) {
+        const int64_t i = ovf[2 * (size_t)e];
+        const int group = ovf[2 * (size_t)e + 1];
+        const int cnt = (int)ucount[group];
+        const uint16_t *list = ulist + (size_t)group * ulist_stride;
+        const XT *x = X + i * ldx;
+        Best<1> best;
+        best.init();
+        for (int l = tid; l < cnt; l += 256) {  // (ascending per thread)
+            const int j = (int)list[l];
+            const double *w = W + (int64_t)j * d;
+            double acc = 0.0;
+            for (int k = 0; k < d; k += 16) {  // (d % 16 == 0; the loads of a block first)
+                double wv[16], xv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { wv[u] = w[k + u]; xv[u] = widen(x[k + u]); }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = fma(wv[u], xv[u], acc);
+            }
+            double rv = (xx[i] + (-2.0 * acc)) + ww[j];
+            if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
+            best.push(rv, j);
+        }
+        sv[tid] = best.v[0];
+        sj[tid] = best.j[0];
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w && lex_lt(sv[tid + w], sj[tid + w], sv[tid], sj[tid])) { sv[tid] = sv[tid + w]; sj[tid] = sj[tid + w]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            double dv = sqrt(sv[0]);
+            if (round_f32) dv = (double)(float)dv;
+            idx_out[i] = (sj[0] == 0x7fffffff) ? (int64_t)-1 : (int64_t)sj[0];
+            dist_out[i] = dv;
+        }
+        __syncthreads();
+    }
 }

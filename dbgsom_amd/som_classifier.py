@@ -59,7 +59,12 @@ class SomClassifier(BaseSom, TransformerMixin, ClassifierMixin):
             for sample, w in zip(X, winners):
                 attrs = self.som_.nodes[self.neurons_[w]]
                 if "som" in attrs:
-                    rows.append(attrs["som"].predict_proba(sample[None, :])[0])
+                    # (a child map knows the classes of its Voronoi set only, by this map's class CODES --
+                    #  what _grow_vertical hands it as y: back into this map's columns)
+                    child = attrs["som"]
+                    row = np.zeros(self.classes_.shape[0])
+                    row[np.asarray(child.classes_, dtype=np.int64)] = child.predict_proba(sample[None, :])[0]
+                    rows.append(row)
                 else:
                     rows.append(attrs["probabilities"])
             return np.array(rows)

@@ -66,9 +66,10 @@ extern "C" {
 #define DBGSOM_PRUNE_RETRY 0x800
 /* per-SAMPLE refinement in front of the exact stage: the four int8 digit products of the top two digit
  * planes over each workgroup's candidate list leave every sample the few prototypes a certified bound
- * cannot separate (<= 4, else its whole list); the float64 chain then runs on those (sample, prototype)
- * pairs alone, on the vector ALU, with the gathered rows streamed once.  Workgroups whose lists do not
- * fit the refinement's tile (192 entries) go through the matrix-core stage as without the flag. */
+ * cannot separate (<= 4, else its whole list); the samples are bucketed again by their likely winner and
+ * the float64 chain runs on those (sample, prototype) pairs alone, on the vector ALU, with the gathered
+ * rows streamed once.  Workgroups whose lists do not fit the refinement's tile (256 entries) go through
+ * the matrix-core stage as without the flag. */
 #define DBGSOM_REFINE 0x1000
 
 /* prototype-count limit of the accumulate step (per-block LDS histogram) */
@@ -186,8 +187,10 @@ int dbgsom_bmu_filtered_counts_async(const void *workspace_dev, int64_t N, int64
                                      uint32_t *counts_host, int64_t n_counts, void *stream);
 
 /* diagnostics of the per-sample refinement (DBGSOM_REFINE) of the last filtered call:
- * out4 = [(sample, prototype) pairs evaluated exactly, workgroups refined, workgroups left to the
- * matrix-core stage, 0]; synchronises the stream */
+ * out4 = [(sample, prototype) pairs evaluated exactly, 128-sample workgroups refined (the others went
+ * through the matrix-core stage), samples whose candidates did not fit four slots (evaluated against
+ * their workgroup's whole list), distinct candidates summed over the pair kernel's 64-sample workgroups];
+ * synchronises the stream */
 int dbgsom_bmu_filtered_refine_counts(const void *workspace_dev, int64_t N, int64_t d, int64_t M,
                                       uint64_t *out4, void *stream);
 

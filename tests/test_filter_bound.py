@@ -221,3 +221,44 @@ def test_top_plane_stands_for_the_row_within_its_bound(name):
         res = np.abs(A - s[:, None] * d0 / 127.0)
         assert (res <= s[:, None] * PLANE0_ERR).all()
         assert np.sqrt((res ** 2).sum(1)).max() <= (np.sqrt(A.shape[1]) * s * PLANE0_ERR).max()
+
+
+# ---- the refinement's bound (csrc/refine.h): top two digit planes = a 16-bit rounding of the row ------
+F16 = 127.0 * 256.0
+
+
+def plane16(A):
+    (d0, d1, _), s, _ = slice_rows(A)
+    q16 = d0 * 256 + d1
+    A16 = s[:, None] * q16 / F16
+    res = np.sqrt(((np.asarray(A, dtype=np.float64) - A16) ** 2).sum(axis=1))
+    return q16, s, res
+
+
+@pytest.mark.parametrize("name", [c[0] for c in CASES])
+def test_refinement_bound_holds_and_keeps_every_possible_winner(name):
+    """v_ij = |w_j|^2 - 2 s_i t_j T / F16^2 with T = sum Q16x Q16w (exact integers);
+    |v_ij + |x_i|^2 - r_ij| <= eps_i = 2 [rx_i (max|w| + max rw) + |x_i| max rw] + rounding, and the rule
+    v_ij <= min_j v_ij + 2 eps_i keeps the arg-min and everything tied with it."""
+    rng = np.random.default_rng(abs(hash(name)) % 2 ** 32 + 1)
+    X, W = dict((c[0], c[1]) for c in CASES)[name](rng)
+    X = np.asarray(X, dtype=np.float32).astype(np.float64)
+    W = np.asarray(W, dtype=np.float64)
+    W[1] = W[0]                                     # an exact tie
+    qx, sx, rx = plane16(X)
+    qw, tw, rw = plane16(W)
+    T = (qx.astype(object) @ qw.T.astype(object)).astype(np.float64)   # exact (python integers)
+    xx, yy = (X ** 2).sum(1), (W ** 2).sum(1)
+    v = yy[None, :] - 2.0 * sx[:, None] * tw[None, :] * T / (F16 * F16)
+    r = exact_r(X, W)
+    d = X.shape[1]
+    wn, rwm = np.sqrt(yy.max()), rw.max()
+    eps = 2.0 * (rx * (wn + rwm) + np.sqrt(xx) * rwm) * (1 + 1e-9) + 4.0 * (d + 16) * 1.1102230246251565e-16 * (xx + yy.max())
+    err = np.abs(v + xx[:, None] - r)
+    assert (err <= eps[:, None]).all(), float((err / eps[:, None]).max())
+    keep = v <= v.min(axis=1)[:, None] + 2 * eps[:, None]
+    best = r.min(axis=1)
+    assert (keep | (r > best[:, None])).all()       # every arg-min (ties included) is kept
+    # the filter is sharp where prototypes are apart: mean candidates per sample stays small on blobs
+    if name == "blobs":
+        assert keep.sum(axis=1).mean() < 3.0

@@ -5,6 +5,14 @@ import pytest
 
 from tests import golden_inputs as gi
 
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
 pytestmark = pytest.mark.gpu
 
 
@@ -164,6 +172,44 @@ def test_vertical_growth_on_device_subsets_matches_the_recorded_tree():
     assert any("som" in est32.som_.nodes[n] for n in est32.neurons_)
 
 
+def test_entropy_vertical_growth_on_device_subsets_matches_the_host_path():
+    """SomClassifier(vertical_growth=True, growth_criterion="entropy"): a child map fitted on a device
+    subset re-codes its labels (np.unique of the subset's classes) while the subset context inherited
+    the PARENT's codes -- the child's own codes must be attached, or the class histograms drop every
+    sample whose parent code is >= the child's class count (round-2 advisor finding).  The tree must
+    equal the one the host path (X[mask], labels re-coded and uploaded) builds."""
+    from dbgsom_amd import SomClassifier
+    from oracle.som_oracle import OracleBackend
+
+    rng = np.random.default_rng(11)
+    centres = rng.normal(size=(6, 12)) * 1.5
+    lab = rng.integers(0, 6, size=2400)
+    X = centres[lab] + rng.normal(size=(2400, 12)) * 1.6   # overlapping classes: mixed neurons
+    y = np.array(["a", "b", "c", "d", "e", "f"])[lab]
+    # (on the host path this grows 7 child maps, five of them on class sets that skip a parent code)
+    kw = dict(random_state=1, n_iter=16, max_neurons=6, vertical_growth=True, growth_criterion="entropy",
+              spreading_factor=0.2, min_samples_vertical_growth=150)
+    dev = SomClassifier(**kw).fit(X, y)
+    host = SomClassifier(backend=OracleBackend(), **kw).fit(X, y)
+    n_children = [0]
+
+    def walk(a, b, path):
+        assert a.neurons_ == b.neurons_, path
+        assert list(a.classes_) == list(b.classes_), path
+        np.testing.assert_allclose(a.weights_, b.weights_, rtol=1e-8, atol=1e-10)
+        for i, node in enumerate(a.neurons_):
+            ca, cb = a.som_.nodes[node].get("som"), b.som_.nodes[node].get("som")
+            assert (ca is None) == (cb is None), path + [i]
+            if ca is not None:
+                n_children[0] += 1
+                walk(ca, cb, path + [i])
+
+    walk(dev, host, [])
+    assert n_children[0] >= 1, "the case must grow vertically"
+    # a child whose classes are a proper subset with a non-prefix code set is what used to break
+    assert np.array_equal(dev.predict(X[:200]), host.predict(X[:200]))
+
+
 def test_bench_under_torchrun_single_rank_rccl():
     """Rehearsal of the multi-GPU launch on a one-GPU box: torch.distributed.run with one rank,
     the RCCL group is created and the per-epoch all-reduce is actually issued
@@ -176,7 +222,7 @@ def test_bench_under_torchrun_single_rank_rccl():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DBGSOM_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
            "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "c2", "--cpu-sample", "0",
            "--fine-phase", "0"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -199,7 +245,7 @@ def test_bench_two_ranks_strong_scaling_rehearsal_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DBGSOM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "c2", "--fine-phase", "0"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]

@@ -1073,3 +1073,145 @@ def test_filtered_search_with_non_finite_prototype_rows(planes):
     r = fi.epoch(W, hop, 1.0, 1e-3, "aligned", True)
     assert np.array_equal(r.winners, q.winners) and np.array_equal(r.distances, q.distances), planes
     ex.release(); fi.release()
+
+
+# ---- per-sample refinement of the candidate lists (filter.hip section 2d, csrc/refine.h) ---------------
+@pytest.mark.parametrize("dt", ["f32", "f64", "bf16"])
+@pytest.mark.parametrize("planes", [0, 4])
+def test_refined_search_is_identical_to_exact(o, dt, planes):
+    """refine = 1: the four int8 digit products of the top two planes over each workgroup's list leave a
+    sample its few possible winners, the samples are bucketed again by the likely one and the float64
+    chain runs on the (sample, prototype) pairs alone.  Winners, distances and new prototypes are those
+    of the all-pairs kernel and of the oracle bit for bit -- behind the sweep and behind the pruning
+    form, stateless and hinted, for the three storage types (bfloat16 rows are streamed as stored),
+    with duplicated prototypes (ties, and more than four inseparable candidates: the overflow path)."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(17)
+    N, d, rows, cols = 30_000, 208, 20, 21           # d % 64 != 0: a partial last tile of the pair kernel
+    M = rows * cols
+    hop = gi.lattice_hops(rows, cols)
+    X, _ = gi.blobs_f32(N, d, 77)
+    X = X.astype(np.float64) if dt == "f64" else X
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    W[11] = W[5]                                      # a tie: the lower index wins
+    W[40:47] = W[39]                                  # seven copies: more candidates than slots
+    storage = "bf16" if dt == "bf16" else None
+    ex = HipBackend(algorithm="exact").load(X, storage=storage)
+    fi = HipBackend(algorithm="filtered").load(X, storage=storage)
+    fi.refine = 1
+    fi.sweep_planes = planes
+    saw_overflow = False
+    for e in range(4):
+        re_ = ex.epoch(W, hop, 2.0, 1e-3, "compact", True)
+        rf = fi.epoch(W, hop, 2.0, 1e-3, "compact", True)
+        assert fi.filter_log[-1][0] == "filtered" and fi.refined
+        assert np.array_equal(rf.winners, re_.winners), e
+        assert np.array_equal(rf.distances, re_.distances), e
+        assert np.array_equal(rf.new_weights, re_.new_weights, equal_nan=True), e
+        pairs, groups, overflow, _ = fi.refine_counts()
+        assert groups == (N + 127) // 128 and N - overflow <= pairs <= 4 * N
+        saw_overflow |= overflow > 0
+        if e == 0:
+            Xr = X
+            if dt == "bf16":
+                import torch
+                Xr = torch.from_numpy(X).to(torch.bfloat16).float().numpy()
+            pick = rng.choice(N, 1500, replace=False)
+            rd, ri = o.bmu_chain(Xr[pick], W, 1)
+            assert np.array_equal(rf.winners[pick], ri) and np.array_equal(rf.distances[pick], rd)
+        fi.algorithm = "filtered_hint"
+        W = np.nan_to_num(re_.new_weights)
+        W[11] = W[5]
+        W[40:47] = W[39]
+    assert saw_overflow, "the duplicated prototypes must exercise the overflow kernel"
+    ex.release(); fi.release()
+
+
+@pytest.mark.parametrize("N,d,M,kind", [(100, 48, 200, "blobs"), (129, 16, 129, "blobs"), (5000, 784, 700, "iso"),
+                                          (4000, 64, 1500, "iso"), (6000, 2048, 300, "blobs"), (3000, 32, 4000, "iso")])
+def test_refinement_at_the_edges_of_its_shapes(N, d, M, kind):
+    """Fewer samples than a workgroup, lists in every tile class of the refinement, lists in two
+    segments (isotropic data behind the pruning form: the whole map is a candidate -- up to 512 entries
+    are refined in two passes), lists beyond that (left to the matrix-core stage), long rows."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(N + d)
+    if kind == "blobs":
+        X, _ = gi.blobs_f32(N, d, N + M)
+    else:
+        X = rng.normal(size=(N, d)).astype(np.float32)
+    W = X[rng.choice(N, M, replace=M > N)].astype(np.float64) + (rng.normal(size=(M, d)) * 1e-3 if M > N else 0.0)
+    hop = np.zeros((M, M))
+    ex = HipBackend(algorithm="exact").load(X)
+    for planes in (4, 2):
+        fi = HipBackend(algorithm="filtered").load(X)
+        fi.refine = 1
+        fi.sweep_planes = planes
+        for e in range(2):
+            re_ = ex.epoch(W, hop, 1.0, 1e-3, "aligned", True)
+            rf = fi.epoch(W, hop, 1.0, 1e-3, "aligned", True)
+            assert fi.filter_log[-1][0] == "filtered"
+            assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances)
+            assert np.array_equal(rf.new_weights, re_.new_weights, equal_nan=True)
+        fi.release()
+    ex.release()
+
+
+def test_refinement_with_non_finite_rows_and_extreme_scales():
+    """A prototype row with a NaN or an infinity (dead neurons of the aligned layout) has no residual
+    norm: the bound is void and every candidate is kept (overflow path); sample rows spanning dozens of
+    decades keep the bound honest in float32."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(3)
+    N, d, M = 12_000, 96, 260
+    X, _ = gi.blobs_f32(N, d, 9)
+    X *= np.exp(rng.uniform(-20, 12, size=(N, 1))).astype(np.float32)
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    hop = np.zeros((M, M))
+    for bad in (None, np.nan, np.inf):
+        Wb = W.copy()
+        if bad is not None:
+            Wb[17, 3] = bad
+            Wb[200] = bad
+        ex = HipBackend(algorithm="exact").load(X)
+        fi = HipBackend(algorithm="filtered").load(X)
+        fi.refine = 1
+        for planes in (4, 1, 3):
+            fi.sweep_planes = planes
+            re_ = ex.epoch(Wb, hop, 1.0, 1e-3, "aligned", True)
+            rf = fi.epoch(Wb, hop, 1.0, 1e-3, "aligned", True)
+            assert np.array_equal(rf.winners, re_.winners) and np.array_equal(rf.distances, re_.distances, equal_nan=True)
+            assert np.array_equal(rf.new_weights, re_.new_weights, equal_nan=True)
+        ex.release(); fi.release()
+
+
+def test_refinement_is_chosen_by_measurement():
+    """refine = 2 (the default): the engine times the exact stage of the first training epochs of a map
+    size with and without the refinement and keeps the faster form; results never depend on it."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(8)
+    N, d, rows, cols = 200_000, 1024, 40, 40          # long rows, long lists: the refinement's ground
+    M = rows * cols
+    c = rng.normal(size=(12, d)).astype(np.float32) * 4
+    X = c[rng.integers(0, 12, N)] + rng.normal(size=(N, d)).astype(np.float32)
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    hop = gi.lattice_hops(rows, cols)
+    fi = HipBackend(algorithm="filtered").load(X)
+    assert fi.refine == 2
+    fi.set_weights(W)
+    from dbgsom_amd.backend import RESIDENT
+    seen = []
+    ref = None
+    for e in range(16):   # (the policy of the candidate lists -- seeds, digit planes -- settles first: every
+        r = fi.epoch(RESIDENT, hop, 3.0, 1e-4, "compact", True, keep_on_device=True, frozen=True)  # change of
+        seen.append(fi.refined)                                   # the lists by a quarter measures again)
+        if ref is None:
+            ref = r
+        assert np.array_equal(r.winners, ref.winners) and np.array_equal(r.distances, ref.distances)
+    assert seen[0] is False            # nothing is known about the lists yet
+    assert True in seen[1:] and False in seen[1:], (seen, fi.filter_log)   # both forms were timed
+    assert len(set(seen[-3:])) == 1, (seen, fi.filter_log)    # settled
+    fi.release()

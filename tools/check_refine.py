@@ -34,7 +34,7 @@ for name in args or ["c2"]:
     hop = bench.lattice_hops(rows, cols)
     sigma = 0.2 * np.sqrt(M)
     results = {}
-    variants = [("refine=0", algo, False), ("refine=1", algo, True)]
+    variants = [("refine=0", algo, 0), ("refine=1", algo, 1), ("refine=2", algo, 2)]
     if with_exact:
         variants.append(("exact", "exact", False))
     for label, alg, refine in variants:
@@ -61,9 +61,11 @@ for name in args or ["c2"]:
         if alg != "exact":
             c = hip.filter_counts()
             extra = f" lists mean {c.mean():.1f} max {c.max()} planes {int(info[2])}"
-            if refine:
-                pairs, ok, left = hip.refine_counts()
-                extra += f" | pairs/sample {pairs / n:.3f} refined {ok} left {left}"
+            extra += f" refined {int(hip.refined)}"
+            if hip.refined:
+                pairs, ok, ovf, nun = hip.refine_counts()
+                extra += (f" | pairs/sample {pairs / n:.3f} refined {ok} of {(n + 127) // 128} overflow samples {ovf} "
+                          f"distinct candidates per 64 samples {nun / ((n + 63) // 64):.1f}")
         print(f"{name} {label:9s} {ms:8.3f} ms/epoch  phases " + " ".join(f"{v:.3f}" for v in ph) + extra, flush=True)
         results[label] = (res.winners.copy(), res.distances.copy(), res.new_weights.copy())
         hip.release()
