@@ -124,16 +124,41 @@ def make_shard(torch, n, d, seed, device, rank=0, kind="blobs"):
     return X
 
 
-def make_shard_numpy(n, d, seed, kind="blobs"):
-    """The same distributions from NumPy on the host (`--via ctx`: no torch anywhere)."""
+def make_shard_numpy(n, d, seed, kind="blobs", rank=0):
+    """`numpy.random.default_rng(seed)` on the host, reproducible on any box.  blobs: 32
+    centres ~ N(0, 16 I) from the stream `seed` (ONE set for the whole data set), unit noise, labels
+    uniform; the rows of rank r come from the stream `seed + r` (rank 0 goes on with the stream that
+    drew the centres).  iso: one isotropic Gaussian.  nonneg: clip(blobs, 0), scaled to [0, 255],
+    standardised."""
     rng = np.random.default_rng(seed)
     centers = rng.standard_normal((32, d)).astype(np.float32) * 4.0
+    if rank:
+        rng = np.random.default_rng(seed + rank)
     X = np.empty((n, d), dtype=np.float32)
     step = 100_000
     for s in range(0, n, step):
         m = min(step, n - s)
         noise = rng.standard_normal((m, d), dtype=np.float32)
         X[s:s + m] = noise if kind == "iso" else centers[rng.integers(0, 32, m)] + noise
+    if kind == "nonneg":
+        np.clip(X, 0, None, out=X)
+        X *= 255.0 / float(X.max())
+        mean, std = X.mean(axis=0), X.std(axis=0)
+        X -= mean
+        X /= np.maximum(std, 1e-6)
+    return X
+
+
+def make_shard_device(torch, n, d, seed, device, rank=0, kind="blobs"):
+    """make_shard_numpy, uploaded (the rows are generated on the host so that any box can regenerate the
+    very inputs of a bench line; DBGSOM_BENCH_DATA=torch: the device generator of rounds 1-2, faster)."""
+    if os.environ.get("DBGSOM_BENCH_DATA", "numpy") == "torch":
+        return make_shard(torch, n, d, seed, device, rank, kind)
+    X = torch.empty((n, d), dtype=torch.float32, device=device)
+    Xh = make_shard_numpy(n, d, seed, kind, rank)
+    step = 250_000
+    for s0 in range(0, n, step):
+        X[s0:s0 + step] = torch.from_numpy(Xh[s0:s0 + step]).to(device)
     return X
 
 
@@ -187,6 +212,7 @@ def cpu_baseline(Xs, W, hop, sigma, gamma, n_full):
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         blas_threads = None
+    cpu_baseline.sample = (ns, win, dist)   # for the parity gate of the same line
     return {
         "value": n_full / t_epoch,
         "unit": "samples/s/epoch",
@@ -202,6 +228,47 @@ def cpu_baseline(Xs, W, hop, sigma, gamma, n_full):
                                             f"{rows_b * M * d * 8 / 2**30:.2f} GiB temporary), x M/rows; "
                                             f"equal to the matmul form: {same}"},
     }
+
+
+def parity_gate(X, W0, hop, sigma, gamma, info, Wn_hip, xbytes):
+    """BASELINE.md 3 / SURVEY.md 8(d) "parity gates reported with every number", in the bench line itself:
+    (1) the HIP winners of the rows the CPU leg searched (>= 5e5 at C4 on a bench host) against the
+    reference path's own engine (sklearn NearestNeighbors on f32 X / f64 W; the oracle's chain form where
+    sklearn is missing) -- indices identical, squared distances to 1e-9 of their scale; (2) the new prototypes of the WHOLE epoch
+    against the oracle's update (per-neuron sums, Voronoi centres, neighbourhood smoothing in NumPy float64)
+    fed the HIP winners and distances of all N rows -- north_star bound 1e-5, float64 builds reach 1e-10."""
+    from oracle import som_oracle as o
+
+    ns, win_cpu, dist_cpu = cpu_baseline.sample
+    win, dist = info["winners"], info["distances"]
+    differ = np.flatnonzero(win[:ns] != win_cpu)
+    mism, ties = int(differ.size), 0
+    if differ.size:
+        # the reference's engine leaves the summation order of x.w to BLAS: two prototypes within its
+        # rounding of each other may swap.  Such a row is no mismatch when the HIP winner is the order-pinned
+        # oracle's (bit for bit) and the engine's own winner is as near to 1e-9.
+        Xd = (X[differ].float() if xbytes == 2 else X[differ]).cpu().numpy()
+        rd, ri = o.bmu_chain(Xd, W0, 1)
+        tie = (win[differ] == ri) & (np.abs(dist_cpu[differ] - rd) <= 1e-9 * np.maximum(rd, 1e-300))
+        ties = int(tie.sum())
+        mism -= ties
+    # squared distances, against the scale of the terms they are the difference of: the engine forms
+    # |x|^2 - 2 x.w + |w|^2 in BLAS order, so a sample that IS a prototype comes out at ~1e-6 instead of 0
+    scale = float(np.median(dist_cpu ** 2)) if ns else 1.0
+    d_err = float(np.max(np.abs(dist[:ns] ** 2 - dist_cpu ** 2) / (dist_cpu ** 2 + scale))) if ns else 0.0
+    M = W0.shape[0]
+    Xh = X.float().cpu().numpy() if xbytes == 2 else X.cpu().numpy()
+    kw = o.exp_similarity_gamma(dist, gamma)
+    S, K, a, E = o.accumulate_numpy(Xh, win, kw, dist, M)
+    Wn = o.smooth_matmul(o.gaussian_neighborhood(hop, sigma), a, o.voronoi_centers(S, K, a, "compact"))
+    scale = np.maximum(np.abs(Wn), 1e-12 * np.abs(Wn).max())
+    w_err = float(np.nanmax(np.abs(Wn_hip - Wn) / scale))
+    nan_same = bool(np.array_equal(np.isnan(Wn_hip), np.isnan(Wn)))
+    ok = mism == 0 and d_err <= 1e-9 and w_err <= 1e-5 and nan_same
+    return {"rows_checked": int(ns), "bmu_mismatches": mism, "bmu_ties_within_blas_rounding": ties,
+            "dist2_rel_err_max": d_err,
+            "w_rows_checked": int(win.size), "w_rel_err_max": w_err, "w_bound": 1e-5, "ok": bool(ok),
+            "reference_engine": "sklearn NearestNeighbors (the reference's call) + oracle update in NumPy float64"}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -220,7 +287,7 @@ def list_flops(counts, n, d):
     return float((2.0 * rows * counts * d).sum()), float((2.0 * 128.0 * padded * d).sum())
 
 
-def rooflines(workload, n, d, M, xbytes, ph, planes, counts):
+def rooflines(workload, n, d, M, xbytes, ph, planes, counts, refined=False):
     """One entry per dominant stage of the filtered epoch, each reproducible from profiles/:
     achieved = ALGORITHMIC work of one launch / its HIP-event duration in this run."""
     flops = 2.0 * n * M * d
@@ -245,7 +312,17 @@ def rooflines(workload, n, d, M, xbytes, ph, planes, counts):
                     "frac": ach / I8_MFMA_PEAK_TOPS, "kernel_ms": ph["sweep"],
                     "digit_products": SWEEP_PRODUCTS[planes], "traffic": traffic,
                     "traffic_source": src, "algorithmic_bytes": float(n) * d})
-    if ph["exact_on_candidates"] > 0 and counts is not None:
+    if ph["exact_on_candidates"] > 0 and refined:
+        # refinement (the top two int8 digit planes of the gathered rows, once) + float64 chain on the
+        # (sample, candidate) pairs (the stored rows, once): both stream X, HBM-bound
+        nbytes = float(n) * d * (2 + xbytes)
+        gbps = nbytes / (ph["exact_on_candidates"] * 1e-3) / 1e9
+        out.append({"stage": "exact search on candidates: per-sample refinement + chain on pairs",
+                    "kernel": "refine_i8_kernel + bucket sort + pair_exact_kernel", "bound": "hbm",
+                    "dtype": "i8 digit products, f64 chain", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": gbps / HBM_PEAK_GBPS, "kernel_ms": ph["exact_on_candidates"], "traffic": None,
+                    "algorithmic_bytes": nbytes})
+    elif ph["exact_on_candidates"] > 0 and counts is not None:
         useful, padded = list_flops(counts, n, d)
         t = ph["exact_on_candidates"] * 1e-3
         traffic, src = measured_traffic(workload, "subset_exact")
@@ -405,10 +482,17 @@ class Harness:
             step_fn()
         self.sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        marks = []
+        for _ in range(steps):   # (a step = one BLOCKING call of the C ABI: its end is a synchronisation)
             step_fn()
+            marks.append(time.perf_counter())
         self.sync()
         elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        per = np.diff(np.array([t0] + marks))
+        t = self.torch.tensor(per, dtype=self.torch.float64, device=self.coll_device())
+        if self.grouped:
+            self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        self.step_seconds = t.cpu().numpy()   # of the last timed regime, max over ranks per step
         be._set("timing", 1)
         be.phase_log = []
         for _ in range(min(steps, 5)):
@@ -418,7 +502,7 @@ class Harness:
         return elapsed, dict(zip(PHASES, log.mean(axis=0).tolist()))
 
 
-def frozen_map_regime(h, algorithm, X, W0, hop, sigma, gamma, steps=None, warmup=None):
+def frozen_map_regime(h, algorithm, X, W0, hop, sigma, gamma, steps=None, warmup=None, assignments=False):
     """every step = one full epoch from the SAME frozen prototypes (resident in HBM,
     DBGSOM_EPOCH_FROZEN), new prototypes stay in HBM."""
     from dbgsom_amd.backend import RESIDENT, HipBackend
@@ -433,12 +517,20 @@ def frozen_map_regime(h, algorithm, X, W0, hop, sigma, gamma, steps=None, warmup
 
     elapsed, phases = h.timed_epochs(be, step, h.args.warmup if warmup is None else warmup,
                                      h.args.steps if steps is None else steps)
-    info = {"filter_log": be.filter_log[-1] if be.filter_log else None}
+    info = {"filter_log": be.filter_log[-1] if be.filter_log else None, "step_seconds": h.step_seconds.copy()}
     counts = None
     if be.filter_log and be.filter_log[-1][0] == "filtered":
         counts = be.filter_counts()
         info["sweep_planes"] = int(be.filter_log[-1][2])
         info["candidates_per_workgroup"] = count_stats(counts)
+        info["refined"] = bool(be.refined)
+        if be.refined:
+            pairs, groups, overflow, distinct = be.refine_counts()
+            info["refinement"] = {"pairs_per_sample": pairs / be.n_samples, "workgroups_refined": groups,
+                                  "overflow_samples": overflow}
+    if assignments:   # one more (untimed) epoch of the same regime that also brings back winners and distances
+        res = be.epoch(RESIDENT, hop, sigma, gamma, "compact", True, keep_on_device=True, frozen=True)
+        info["winners"], info["distances"] = res.winners, res.distances
     Wn = be.get_weights(1)   # the output of the last (frozen) epoch
     be.release()
     del M
@@ -487,9 +579,9 @@ def other_data_regime(h, torch, device, name):
     `exact`: which search `auto` settles on, how long the candidate lists are, and the rate."""
     n, d, rows, cols, seed, kind, cfg_name = WORKLOADS[name]
     M = rows * cols
-    X = make_shard(torch, n, d, seed, device, 0, kind)
-    g = torch.Generator(device=device).manual_seed(seed + 7)
-    W0 = X[torch.randperm(n, device=device, generator=g)[:M]].double().cpu().numpy()
+    X = make_shard_device(torch, n, d, seed, device, 0, kind)
+    sel = torch.from_numpy(np.random.default_rng(seed + 7).choice(n, M, replace=False)).to(device)
+    W0 = X[sel].double().cpu().numpy()
     gamma = float(1.0 / X.double().var(dim=0, unbiased=False).sum().item())
     hop, sigma = lattice_hops(rows, cols), 0.2 * np.sqrt(M)
     out = {"workload": cfg_name}
@@ -590,7 +682,7 @@ def main():
     else:
         n_gpu, n_total = n_work, n_work * world
     M = rows * cols
-    X = make_shard(torch, n_gpu, d, seed, device, rank=rank, kind=kind)
+    X = make_shard_device(torch, n_gpu, d, seed, device, rank=rank, kind=kind)
     xbytes = 4
     if args.workload in BF16_WORKLOADS:
         X = X.to(torch.bfloat16)  # storage dtype of the workload; the context keeps it
@@ -616,9 +708,8 @@ def main():
     var = mom[d:2 * d] / nn - (mom[:d] / nn) ** 2
     gamma = float(1.0 / var.sum().item())
     ctl = torch.zeros(M * d, dtype=torch.float64, device=device)
-    if rank == 0:
-        g = torch.Generator(device=device).manual_seed(seed + 7)
-        sel = torch.randperm(n_gpu, device=device, generator=g)[:M]
+    if rank == 0:   # W = M rows of X chosen by default_rng(seed + 7).choice(N, M, replace=False)
+        sel = torch.from_numpy(np.random.default_rng(seed + 7).choice(n_gpu, M, replace=False)).to(device)
         ctl[:] = X[sel].double().reshape(-1)
     if grouped:
         ctl = ctl.to(h.coll_device())
@@ -628,13 +719,15 @@ def main():
     sigma = 0.2 * np.sqrt(M)  # BaseSom.py:876 at epoch 0
 
     results = {}
+    gate = world == 1 and args.cpu_sample > 0   # the parity gate needs the CPU leg's winners
     for algo in dict.fromkeys([args.algorithm, "exact"]):  # headline first, exact always reported
-        results[algo] = frozen_map_regime(h, algo, X, W0, hop, sigma, gamma)
+        results[algo] = frozen_map_regime(h, algo, X, W0, hop, sigma, gamma,
+                                          assignments=gate and algo == args.algorithm)
     fine = fine_phase_regime(h, X, W0, M, hop, gamma, n_total) if args.fine_phase else None
     weak = None
     if world > 1 and args.scaling == "strong" and not args.samples_per_gpu:
         # beside the metric's strong-scaling line: every rank with the workload's full N
-        Xw = make_shard(torch, n_work, d, seed, device, rank=rank, kind=kind)
+        Xw = make_shard_device(torch, n_work, d, seed, device, rank=rank, kind=kind)
         if args.workload in BF16_WORKLOADS:
             Xw = Xw.to(torch.bfloat16)
         el, _, _, _, _ = frozen_map_regime(h, args.algorithm, Xw, W0, hop, sigma, gamma)
@@ -651,22 +744,31 @@ def main():
             roofs, roof = [exact_roof], exact_roof
         else:
             roofs = rooflines(args.workload if n_gpu == n_work else None, n_gpu, d, M, xbytes, phases,
-                              int(info.get("sweep_planes", 1)), counts)
+                              int(info.get("sweep_planes", 1)), counts, bool(info.get("refined")))
             # the dominant kernel of the step = the longest stage that is one kernel family
             roof = max(roofs[:2], key=lambda r: r["kernel_ms"]) if len(roofs) >= 2 else roofs[0]
+        med = float(np.median(info["step_seconds"]))    # the median epoch (max over ranks per step)
+        e_med = float(np.median(results["exact"][2]["step_seconds"]))
         out = {
             "metric": "samples/sec/epoch (BMU+update)",
-            "value": n_total * args.steps / elapsed,
+            "value": n_total / med,
             "unit": "samples/s/epoch",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": med * 1e3,
+            "ms_per_step_mean": elapsed / args.steps * 1e3,   # the bracketed total / steps
+            "value_definition": "N / median step time of the K timed steps (max over ranks per step)",
             "higher_is_better": True,
             "scaling": "weak" if (args.scaling == "weak" or args.samples_per_gpu) else "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": ("synthetic: numpy.random.default_rng(%d [+ rank]) Gaussian blobs, SURVEY.md 8(d)" % seed
+                     if os.environ.get("DBGSOM_BENCH_DATA", "numpy") != "torch" else "synthetic (torch device generator)"),
+            # the data-independent floor (all-pairs search, the same inputs) and both against F_A = 2 N M d
+            "floor": n_total / e_med,
+            "frac_vs_2NMd": 2.0 * n_total * M * d / med / 1e12 / (F64_MFMA_PEAK_TFLOPS * world),
+            "floor_frac_vs_2NMd": 2.0 * n_total * M * d / e_med / 1e12 / (F64_MFMA_PEAK_TFLOPS * world),
             "config": {"workload": cfg_name, "samples_total": n_total, "samples_per_gpu": n_gpu,
                        "features": d, "prototypes": M,
                        "x_storage": "bf16" if args.workload in BF16_WORKLOADS else "f32",
@@ -681,9 +783,10 @@ def main():
         }
         if info.get("candidates_per_workgroup"):
             out["filter"] = {"sweep_planes": info.get("sweep_planes"),
-                             "candidates_per_workgroup": info["candidates_per_workgroup"]}
-        out["exact"] = {"value": n_total * args.steps / e_elapsed,
-                        "ms_per_step": e_elapsed / args.steps * 1e3, "phases_ms": e_phases,
+                             "candidates_per_workgroup": info["candidates_per_workgroup"],
+                             "refined": info.get("refined", False), "refinement": info.get("refinement")}
+        out["exact"] = {"value": n_total / e_med,
+                        "ms_per_step": e_med * 1e3, "phases_ms": e_phases,
                         "roofline": exact_roof,
                         "prototypes_identical_to_headline": bool(np.array_equal(e_Wn, Wn, equal_nan=True))}
         if fine:
@@ -695,9 +798,20 @@ def main():
     if rank == 0:
         if args.cpu_sample > 0 and world == 1:  # the CPU baseline is reported at N = 1 only
             ns = min(args.cpu_sample, X.shape[0])
-            out["cpu_baseline"] = cpu_baseline(X[:ns].float().cpu().numpy(), W0, hop, sigma, gamma, n_gpu)
+            Xs = X[:ns].float().cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(Xs, W0, hop, sigma, gamma, n_gpu)
             out["gpu_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["parity"] = parity_gate(X, W0, hop, sigma, gamma, results[args.algorithm][2],
+                                        results[args.algorithm][4], xbytes)
+        if out.get("other_data"):   # the same step on data without clusters: what the headline owes its data set
+            iso = out["other_data"]["c4iso"]["auto"]
+            out["value_isotropic"] = iso["value"]
+            out["ms_per_step_isotropic"] = iso["ms_per_step"]
         print(json.dumps(out))
+        if out.get("parity") and not out["parity"]["ok"]:
+            sys.stderr.write("bench.py: PARITY GATE FAILED: %r\n" % (out["parity"],))
+            sys.stdout.flush()
+            os._exit(3)
     if grouped:
         td.barrier()
         td.destroy_process_group()

@@ -50,10 +50,11 @@ struct DevBuf {
     int reserve_keep(size_t bytes, size_t keep, hipStream_t s) {
         if (bytes <= cap) return DBGSOM_OK;
         void *old = p;
+        const size_t old_cap = cap;
         p = nullptr;
         cap = 0;
         const int rc = reserve(bytes * 2);
-        if (rc != DBGSOM_OK) { p = old; return rc; }
+        if (rc != DBGSOM_OK) { p = old; cap = old_cap; return rc; }
         if (old && keep) {
             hipError_t e = hipMemcpyAsync(p, old, keep, hipMemcpyDeviceToDevice, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -851,15 +852,19 @@ int dbgsom_ctx_create(int device, dbgsom_ctx **out) {
     return DBGSOM_OK;
 }
 
+// every DevBuf of a context, for dbgsom_ctx_destroy and the "device_bytes" option alike
+#define CTX_DEVBUFS(c)                                                                                             \
+    {&(c)->y, &(c)->hop, &(c)->hop_stage, &(c)->Wb[0], &(c)->Wb[1], &(c)->ww, &(c)->idx[0], &(c)->idx[1], &(c)->dist,  \
+     &(c)->kw, &(c)->sums, &(c)->acc_ws, &(c)->sm_ws, &(c)->filt_ws, &(c)->scal, &(c)->qidx, &(c)->qdist, &(c)->red,  \
+     &(c)->hist, &(c)->stage_dev, &(c)->part_order, &(c)->part_ws, &(c)->part_counts, &(c)->shiftb}
+
 int dbgsom_ctx_destroy(dbgsom_ctx *c) {
     if (!c) return DBGSOM_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->timing) (void)dbgsom_filter_timing(0);
     c->xs.release(); c->xq.release();
-    DevBuf *bufs[] = {&c->y, &c->hop, &c->hop_stage, &c->Wb[0], &c->Wb[1], &c->ww, &c->idx[0], &c->idx[1],
-                      &c->dist, &c->kw, &c->sums, &c->acc_ws, &c->sm_ws, &c->filt_ws, &c->scal, &c->qidx,
-                      &c->qdist, &c->red, &c->hist, &c->stage_dev, &c->part_order, &c->part_ws, &c->part_counts};
+    DevBuf *bufs[] = CTX_DEVBUFS(c);
     for (DevBuf *b : bufs) b->release();
     c->tail.release(); c->counts.release();
     if (c->ev_created) for (auto &e : c->ev) (void)hipEventDestroy(e);
@@ -937,9 +942,7 @@ int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
     else if (!strcmp(name, "device_bytes")) {
         size_t tot = c->xs.own.cap + c->xs.x32.cap + c->xs.xx.cap + c->xs.planes.cap + c->xq.own.cap + c->xq.x32.cap +
                      c->xq.xx.cap + c->xq.planes.cap;
-        DevBuf *bufs[] = {&c->y, &c->hop, &c->hop_stage, &c->Wb[0], &c->Wb[1], &c->ww, &c->idx[0], &c->idx[1],
-                          &c->dist, &c->kw, &c->sums, &c->acc_ws, &c->sm_ws, &c->filt_ws, &c->scal, &c->qidx,
-                          &c->qdist, &c->red, &c->hist, &c->stage_dev, &c->part_order, &c->part_ws, &c->part_counts};
+        DevBuf *bufs[] = CTX_DEVBUFS(c);
         for (DevBuf *b : bufs) tot += b->cap;
         *v = (int64_t)tot;
     } else {
@@ -973,6 +976,9 @@ static void reset_training_state(dbgsom_ctx *c) {
     c->last_filtered = false;
     c->last_mean = NAN;
     c->sumsM = 0;
+    // the resident prototypes were laid out for the old samples' padded row length: gone with them
+    c->M = c->otherM = 0;
+    c->rf_M = -1; c->rf_ms[0] = c->rf_ms[1] = NAN;
 }
 
 int dbgsom_ctx_load(dbgsom_ctx *c, const void *X_host, int x_dtype, int64_t N, int64_t d, int storage) {
