@@ -366,29 +366,84 @@ def count_stats(c):
 # --via ctx: NumPy + ctypes only
 # ---------------------------------------------------------------------------------------------
 def run_via_ctx(args):
-    """The headline step through the raw context-level ABI: no torch, no HipBackend."""
+    """The headline step through the raw context-level ABI: no torch, no HipBackend.  With --gpus N (one
+    process per GPU, launched by torch.distributed.run or anything else that sets RANK / WORLD_SIZE /
+    LOCAL_RANK): the per-epoch collective is RCCL driven by the library itself (dbgsom_ctx_set_rccl);
+    rank 0's ncclUniqueId travels through a file named after MASTER_PORT, written before any GPU call of
+    the other ranks; moments, start prototypes, barriers and timings go through dbgsom_ctx_allreduce_host."""
+    import tempfile
+
     from dbgsom_amd import _native as nat
 
-    n, d, rows, cols, seed, kind, cfg_name = WORKLOADS[args.workload]
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    n_work, d, rows, cols, seed, kind, cfg_name = WORKLOADS[args.workload]
     if args.samples_per_gpu:
-        n = args.samples_per_gpu
+        n, n_total = args.samples_per_gpu, args.samples_per_gpu * world
+    elif args.scaling == "strong":
+        n, n_total = (n_work * (rank + 1)) // world - (n_work * rank) // world, n_work
+    else:
+        n, n_total = n_work, n_work * world
     M = rows * cols
     t_gen = time.perf_counter()
-    X = make_shard_numpy(n, d, seed, kind)
+    X = make_shard_numpy(n, d, seed, kind, rank)
     t_gen = time.perf_counter() - t_gen
-    rng = np.random.default_rng(seed + 7)
-    W0 = X[rng.choice(n, M, replace=False)].astype(np.float64)
-    gamma = float(1.0 / np.var(X[:200_000].astype(np.float64), axis=0).sum())
     hop = lattice_hops(rows, cols)
     sigma = 0.2 * np.sqrt(M)
     ctx = ctypes.c_void_p()
-    nat.call("dbgsom_ctx_create", 0, ctypes.byref(ctx))
+    nat.call("dbgsom_ctx_create", local % max(1, nat.device_count()), ctypes.byref(ctx))
+    comm = ctypes.c_void_p()
     out = {}
+
+    def allsum(v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        nat.call("dbgsom_ctx_allreduce_host", ctx, v.ctypes.data, v.size)
+        return v
+
+    def max_over_ranks(x):
+        v = np.zeros(world)
+        v[rank] = x
+        return float(allsum(v).max())
+
     try:
+        if world > 1 or os.environ.get("DBGSOM_FORCE_COLLECTIVE") == "1":
+            path = os.path.join(tempfile.gettempdir(), "dbgsom_rccl_%s_%s.id" % (
+                os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run")))
+            uid = ctypes.create_string_buffer(128)
+            if rank == 0:
+                nat.call("dbgsom_rccl_unique_id", uid)
+                with open(path + ".tmp", "wb") as fh:
+                    fh.write(uid.raw)
+                os.replace(path + ".tmp", path)
+            else:
+                t_wait = time.time()
+                while not os.path.exists(path):
+                    if time.time() - t_wait > 300:
+                        sys.exit("bench.py: rank 0's ncclUniqueId never arrived at " + path)
+                    time.sleep(0.05)
+                uid = ctypes.create_string_buffer(open(path, "rb").read(), 128)
+            nat.call("dbgsom_rccl_comm_init", uid, world, rank, ctypes.byref(comm))
+            nat.call("dbgsom_ctx_set_rccl", ctx, comm)
+            allsum(np.zeros(1))   # every rank has read the id
+            if rank == 0:
+                os.unlink(path)
         t_up = time.perf_counter()
         st = nat.BF16 if args.workload in BF16_WORKLOADS else nat.F32
         nat.call("dbgsom_ctx_load", ctx, X.ctypes.data, nat.F32, n, d, st)
         t_up = time.perf_counter() - t_up
+        # gamma = 1 / sum of the variances of the WHOLE data set; W = M rows of rank 0's shard
+        Xd = X[:200_000].astype(np.float64)
+        mom = allsum(np.concatenate([Xd.sum(axis=0), (Xd * Xd).sum(axis=0), [Xd.shape[0]]]))
+        del Xd
+        nn = mom[2 * d]
+        gamma = float(1.0 / (mom[d:2 * d] / nn - (mom[:d] / nn) ** 2).sum())
+        W0 = np.zeros((M, d))
+        if rank == 0:
+            W0[:] = X[np.random.default_rng(seed + 7).choice(n, M, replace=False)]
+        W0 = allsum(W0.reshape(-1)).reshape(M, d)
         nat.call("dbgsom_ctx_set_topology", ctx, hop.ctypes.data, M)
         chg, E, a = np.empty(1), np.empty(M), np.empty(M)
         Wn = {}
@@ -405,10 +460,17 @@ def run_via_ctx(args):
                 step()
             ms = (ctypes.c_double * 8)()
             acc = np.zeros(8)
+            allsum(np.zeros(1))   # barrier (every call of the ABI is blocking: the GPU is idle behind it)
             t0 = time.perf_counter()
+            marks = []
             for _ in range(args.steps):
                 step()
-            elapsed = time.perf_counter() - t0
+                marks.append(time.perf_counter())
+            allsum(np.zeros(1))
+            elapsed = max_over_ranks(time.perf_counter() - t0)
+            per = np.zeros((world, args.steps))
+            per[rank] = np.diff(np.array([t0] + marks))
+            per = allsum(per.reshape(-1)).reshape(world, args.steps).max(axis=0)
             nat.call("dbgsom_ctx_set_option", ctx, b"timing", 1)
             for _ in range(3):   # phase times from three more (untimed) steps with HIP events
                 step()
@@ -416,20 +478,28 @@ def run_via_ctx(args):
                 acc += np.array(list(ms)) / 3
             Wn[algo] = np.empty((M, d))
             nat.call("dbgsom_ctx_get_weights", ctx, 1, Wn[algo].ctypes.data, M)
-            out[algo] = (elapsed, dict(zip(PHASES, acc.tolist())))
+            out[algo] = (elapsed, dict(zip(PHASES, acc.tolist())), float(np.median(per)))
     finally:
         nat.call("dbgsom_ctx_destroy", ctx)
-    elapsed, ph = out[args.algorithm]
-    e_elapsed, e_ph = out["exact"]
+        if comm:
+            nat.call("dbgsom_rccl_comm_destroy", comm)
+    if rank != 0:
+        return
+    elapsed, ph, med = out[args.algorithm]
+    e_elapsed, e_ph, e_med = out["exact"]
     line = {
-        "metric": "samples/sec/epoch (BMU+update)", "value": n * args.steps / elapsed,
-        "unit": "samples/s/epoch", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic (NumPy on the host)",
-        "config": {"workload": cfg_name, "samples": n, "features": d, "prototypes": M,
-                   "x_storage": "bf16" if args.workload in BF16_WORKLOADS else "f32",
-                   "map": "frozen (same prototypes every step)", "bmu_algorithm": args.algorithm,
-                   "via": "ctx: dbgsom_ctx_* through ctypes, NumPy host arrays only"},
+        "metric": "samples/sec/epoch (BMU+update)", "value": n_total / med,
+        "unit": "samples/s/epoch", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": med * 1e3, "ms_per_step_mean": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak" if (args.scaling == "weak" or args.samples_per_gpu) else "strong",
+        "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic: numpy.random.default_rng(%d [+ rank]) on the host, SURVEY.md 8(d)" % seed,
+        "config": {"workload": cfg_name, "samples_total": n_total, "samples_per_gpu": n, "features": d,
+                   "prototypes": M, "x_storage": "bf16" if args.workload in BF16_WORKLOADS else "f32",
+                   "sharding": f"rows/{world}", "map": "frozen (same prototypes every step)",
+                   "bmu_algorithm": args.algorithm,
+                   "via": "ctx: dbgsom_ctx_* through ctypes, NumPy host arrays only"
+                          + ("; collective: RCCL inside the library (dbgsom_ctx_set_rccl)" if comm else "")},
         "roofline": exact_roofline(n, d, M, e_ph["bmu"]) if args.algorithm == "exact" else
         {"stage": "whole BMU search", "bound": "mfma", "dtype": "f64-equivalent",
          "achieved": 2.0 * n * M * d / (ph["bmu"] * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TFLOPS,
@@ -437,7 +507,7 @@ def run_via_ctx(args):
          "frac": 2.0 * n * M * d / (ph["bmu"] * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
          "kernel_ms": ph["bmu"]},
         "phases_ms": ph,
-        "exact": {"value": n * args.steps / e_elapsed, "ms_per_step": e_elapsed / args.steps * 1e3,
+        "exact": {"value": n_total / e_med, "ms_per_step": e_med * 1e3,
                   "prototypes_identical_to_headline": bool(np.array_equal(Wn["exact"], Wn[args.algorithm],
                                                                            equal_nan=True))},
         "host_s": {"generate": t_gen, "dbgsom_ctx_load (PCIe upload + norms)": t_up},
@@ -627,8 +697,6 @@ def main():
                          "actual sample is sized for ~15 s of CPU work")
     args = ap.parse_args()
     if args.via == "ctx":
-        if args.gpus != 1:
-            sys.exit("bench.py: --via ctx is the single-GPU NumPy caller")
         return run_via_ctx(args)
 
     import torch

@@ -72,6 +72,11 @@ SIGNATURES = {
     "dbgsom_ctx_set_labels": (_ci, [_vp, _vp, _i64]),
     "dbgsom_ctx_set_topology": (_ci, [_vp, _vp, _i64]),
     "dbgsom_ctx_set_allreduce": (_ci, [_vp, _vp, _vp]),
+    "dbgsom_rccl_unique_id": (_ci, [_vp]),
+    "dbgsom_rccl_comm_init": (_ci, [_vp, _ci, _ci, ctypes.POINTER(_vp)]),
+    "dbgsom_rccl_comm_destroy": (_ci, [_vp]),
+    "dbgsom_ctx_set_rccl": (_ci, [_vp, _vp]),
+    "dbgsom_ctx_allreduce_host": (_ci, [_vp, _vp, _i64]),
     "dbgsom_ctx_set_weights": (_ci, [_vp, _vp, _i64]),
     "dbgsom_ctx_get_weights": (_ci, [_vp, _ci, _vp, _i64]),
     "dbgsom_ctx_read_weight_rows": (_ci, [_vp, _ci, _vp, _i64, _vp]),
@@ -137,9 +142,16 @@ def _load_hip_runtime():
         if os.path.isabs(path) and not os.path.exists(path):
             continue
         try:
-            return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            rt = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
         except OSError as e:  # try the next candidate
             errors.append(f"{path}: {e}")
+            continue
+        # the RCCL that belongs to THIS runtime (dbgsom_ctx_set_rccl resolves librccl at run time): a
+        # librccl built against another libamdhip64 would bring a second HIP runtime into the process
+        rccl = os.path.join(os.path.dirname(path), "librccl.so") if os.path.isabs(path) else ""
+        if rccl and os.path.exists(rccl):
+            os.environ.setdefault("DBGSOM_RCCL_LIB", rccl)
+        return rt
     raise RuntimeError("no HIP runtime (libamdhip64.so) could be loaded: " + "; ".join(errors))
 
 

@@ -200,6 +200,9 @@ class _DeviceArray:
                                          "data": (int(ptr), False), "version": 3, "strides": None}
 
 
+_RCCL_COMMS = {}   # device index -> ncclComm_t made by dbgsom_rccl_comm_init (process lifetime)
+
+
 class HipBackend(HotPathBackend):
     """MI355X backend: one ``dbgsom_ctx`` (one GPU) per instance / process."""
 
@@ -315,6 +318,25 @@ class HipBackend(HotPathBackend):
 
         dev = torch.device("cuda", self.device_index)
         on_device = td.get_backend() == "nccl"
+        if on_device and os.environ.get("DBGSOM_COLLECTIVE", "rccl") != "callback":
+            # RCCL driven by the library itself (dbgsom_ctx_set_rccl): no callback, no interpreter in the
+            # epoch.  One communicator per process and device, made once (torch.distributed only carries
+            # rank 0's 128-byte id to the other ranks) and shared by every context of this process.
+            comm = _RCCL_COMMS.get(self.device_index)
+            if comm is None:
+                uid = ctypes.create_string_buffer(128)
+                if rank == 0:
+                    _native.call("dbgsom_rccl_unique_id", uid)
+                box = [uid.raw]
+                td.broadcast_object_list(box, src=0)
+                uid = ctypes.create_string_buffer(box[0], 128)
+                self._get("n_samples")   # (a context call: this thread is on the context's device)
+                comm = ctypes.c_void_p()
+                _native.call("dbgsom_rccl_comm_init", uid, world, rank, ctypes.byref(comm))
+                _RCCL_COMMS[self.device_index] = comm
+            _native.call("dbgsom_ctx_set_rccl", self._ctx, comm)
+            self._cb = None
+            return
         cache = {}   # the context reuses its stream and (until the map grows) its sums buffer
 
         def reduce(_user, ptr, count, stream):

@@ -7,6 +7,7 @@
 // previous winners as seeds, device-resident prototypes between epochs, the one all-reduce per
 // epoch (through the caller's callback).  No kernels of the hot path in this file: it drives the
 // launchers of bmu*.hip, filter.hip, accumulate.hip, smooth.hip, stats.hip.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -300,9 +301,11 @@ struct dbgsom_ctx {
     const void *last_filter_ws = nullptr;
     // staging
     PinBuf tail, counts;
-    // collective
+    // collective: the caller's callback, or RCCL driven from here
     dbgsom_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
+    void *rccl_comm = nullptr;
+    bool rccl_owned = false;
     // traffic of the prototypes across PCIe (f-4 evidence: whole matrices only at the first epoch, at
     // growth steps and at the end of a fit)
     int64_t w_up_calls = 0, w_up_bytes = 0, w_down_calls = 0, w_down_bytes = 0, w_row_writes = 0, w_row_reads = 0;
@@ -514,7 +517,65 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     return DBGSOM_OK;
 }
 
+// librccl, resolved at run time (no link-time dependency: single-GPU callers never load it)
+struct RcclApi {
+    int (*get_unique_id)(void *id) = nullptr;                                        // ncclGetUniqueId
+    int (*comm_init_rank)(void **comm, int nranks, /* ncclUniqueId by value */ ...) = nullptr;
+    int (*all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*comm_destroy)(void *) = nullptr;
+    const char *(*error_string)(int) = nullptr;
+    bool tried = false, ok = false;
+};
+struct NcclUniqueId { char internal[128]; };   // (rccl.h: ncclUniqueId)
+typedef int (*nccl_comm_init_rank_fn)(void **comm, int nranks, NcclUniqueId id, int rank);
+RcclApi g_rccl;
+nccl_comm_init_rank_fn g_rccl_init = nullptr;
+
+int rccl_load() {
+    if (g_rccl.tried) {
+        if (!g_rccl.ok) { set_error("librccl could not be loaded (see the first failure)"); return DBGSOM_ESTATE; }
+        return DBGSOM_OK;
+    }
+    g_rccl.tried = true;
+    void *h = nullptr;
+    // a copy already in the process (PyTorch's) shares the HIP runtime that is in use: take it
+    if (dlsym(RTLD_DEFAULT, "ncclAllReduce")) h = RTLD_DEFAULT;
+    const char *env = getenv("DBGSOM_RCCL_LIB");
+    const char *names[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *n : names) {
+        if (h) break;
+        if (n && *n) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!h) { set_error("librccl not found (set DBGSOM_RCCL_LIB): %s", dlerror()); return DBGSOM_ESTATE; }
+    g_rccl.get_unique_id = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    g_rccl_init = (nccl_comm_init_rank_fn)dlsym(h, "ncclCommInitRank");
+    g_rccl.all_reduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.comm_destroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    g_rccl.error_string = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.ok = g_rccl.get_unique_id && g_rccl_init && g_rccl.all_reduce && g_rccl.comm_destroy;
+    if (!g_rccl.ok) { set_error("librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy"); return DBGSOM_ESTATE; }
+    return DBGSOM_OK;
+}
+const char *rccl_err(int rc) { return g_rccl.error_string ? g_rccl.error_string(rc) : "?"; }
+void drop_rccl(dbgsom_ctx *c) {
+    if (c->rccl_comm && c->rccl_owned && g_rccl.ok) {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        (void)g_rccl.comm_destroy(c->rccl_comm);
+    }
+    c->rccl_comm = nullptr;
+    c->rccl_owned = false;
+}
+
 int run_allreduce(dbgsom_ctx *c, double *buf, int64_t count) {
+    if (c->rccl_comm) {  // ncclDouble = 8, ncclSum = 0 (rccl.h), in place, on the context's stream
+        const int rc = g_rccl.all_reduce(buf, buf, (size_t)count, 8, 0, c->rccl_comm, c->stream);
+        if (rc != 0) {
+            (void)hipStreamSynchronize(c->stream);
+            set_error("ncclAllReduce failed (%d: %s)", rc, rccl_err(rc));
+            return DBGSOM_ECALLBACK;
+        }
+        return DBGSOM_OK;
+    }
     if (!c->allreduce) return DBGSOM_OK;
     const int rc = c->allreduce(c->allreduce_user, buf, count, (void *)c->stream);
     if (rc != 0) {
@@ -863,6 +924,7 @@ int dbgsom_ctx_destroy(dbgsom_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->timing) (void)dbgsom_filter_timing(0);
+    drop_rccl(c);
     c->xs.release(); c->xq.release();
     DevBuf *bufs[] = CTX_DEVBUFS(c);
     for (DevBuf *b : bufs) b->release();
@@ -1066,8 +1128,60 @@ int dbgsom_ctx_set_topology(dbgsom_ctx *c, const double *hop_host, int64_t M) {
 
 int dbgsom_ctx_set_allreduce(dbgsom_ctx *c, dbgsom_allreduce_fn fn, void *user) {
     CTX_CHECK(c);
+    drop_rccl(c);
     c->allreduce = fn;
     c->allreduce_user = user;
+    return DBGSOM_OK;
+}
+
+int dbgsom_rccl_unique_id(char *id128) {
+    DBGSOM_REQUIRE(id128, "null pointer");
+    TRY(rccl_load());
+    NcclUniqueId id;
+    const int rc = g_rccl.get_unique_id(&id);
+    if (rc != 0) { set_error("ncclGetUniqueId failed (%d: %s)", rc, rccl_err(rc)); return DBGSOM_ECALLBACK; }
+    memcpy(id128, id.internal, 128);
+    return DBGSOM_OK;
+}
+
+int dbgsom_rccl_comm_init(const char *id128, int nranks, int rank, void **comm_out) {
+    DBGSOM_REQUIRE(id128 && comm_out && nranks >= 1 && rank >= 0 && rank < nranks, "bad communicator arguments");
+    TRY(rccl_load());
+    NcclUniqueId id;
+    memcpy(id.internal, id128, 128);
+    void *comm = nullptr;
+    const int rc = g_rccl_init(&comm, nranks, id, rank);
+    if (rc != 0 || !comm) { set_error("ncclCommInitRank failed (%d: %s)", rc, rccl_err(rc)); return DBGSOM_ECALLBACK; }
+    *comm_out = comm;
+    return DBGSOM_OK;
+}
+
+int dbgsom_rccl_comm_destroy(void *comm) {
+    if (!comm) return DBGSOM_OK;
+    TRY(rccl_load());
+    const int rc = g_rccl.comm_destroy(comm);
+    if (rc != 0) { set_error("ncclCommDestroy failed (%d: %s)", rc, rccl_err(rc)); return DBGSOM_ECALLBACK; }
+    return DBGSOM_OK;
+}
+
+int dbgsom_ctx_allreduce_host(dbgsom_ctx *c, double *vals_host, int64_t n) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(vals_host && n >= 1, "bad arguments");
+    if (!c->rccl_comm && !c->allreduce) return DBGSOM_OK;
+    TRY(c->red.reserve((size_t)n * 8));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(c->red.p, vals_host, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    TRY(run_allreduce(c, c->red.as<double>(), n));
+    DBGSOM_HIP_CHECK(hipMemcpyAsync(vals_host, c->red.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
+}
+
+int dbgsom_ctx_set_rccl(dbgsom_ctx *c, void *nccl_comm) {
+    CTX_CHECK(c);
+    if (nccl_comm) TRY(rccl_load());
+    drop_rccl(c);
+    c->rccl_comm = nccl_comm;
+    c->rccl_owned = false;
+    if (nccl_comm) { c->allreduce = nullptr; c->allreduce_user = nullptr; }
     return DBGSOM_OK;
 }
 

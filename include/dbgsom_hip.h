@@ -299,6 +299,28 @@ int dbgsom_ctx_set_topology(dbgsom_ctx *ctx, const double *hop_host, int64_t M);
  * Returns 0 on success; anything else makes the call fail with DBGSOM_ECALLBACK. */
 typedef int (*dbgsom_allreduce_fn)(void *user, double *buf_dev, int64_t count, void *stream);
 int dbgsom_ctx_set_allreduce(dbgsom_ctx *ctx, dbgsom_allreduce_fn fn, void *user);
+/* The same collective issued by the library itself: ncclAllReduce(buf, buf, count, ncclDouble, ncclSum)
+ * on the context's stream, RCCL over xGMI -- no callback, no interpreter in the epoch (what SURVEY.md 5 /
+ * 8(b) asks of the replacement: "the library drives all devices itself").  librccl is resolved at run
+ * time (symbols already in the process -- e.g. the copy a loaded PyTorch brought --, else
+ * $DBGSOM_RCCL_LIB, else librccl.so[.1] of the system ROCm): the library has no link-time dependency on
+ * it and single-GPU callers never load it.
+ *   dbgsom_rccl_unique_id     rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other
+ *                             ranks by whatever launched them (a file, an environment variable, MPI ...)
+ *   dbgsom_rccl_comm_init     every rank, after hipSetDevice / dbgsom_ctx_create on its GPU: a communicator
+ *                             of `nranks` (ncclCommInitRank; collective -- all ranks must call it); it
+ *                             outlives contexts and is destroyed with dbgsom_rccl_comm_destroy
+ *   dbgsom_ctx_set_rccl       the context issues its collective on this communicator (an ncclComm_t as
+ *                             void *: one made above, or any the caller owns); NULL detaches
+ * It replaces a callback set with dbgsom_ctx_set_allreduce (and the other way round). */
+int dbgsom_rccl_unique_id(char *id128);
+int dbgsom_rccl_comm_init(const char *id128, int nranks, int rank, void **comm_out);
+int dbgsom_rccl_comm_destroy(void *comm);
+int dbgsom_ctx_set_rccl(dbgsom_ctx *ctx, void *nccl_comm);
+/* element-wise SUM of `n` host float64 values over the ranks of the context's collective (RCCL or
+ * callback; identity for a single rank): what a caller without a communication library of its own needs
+ * around the epochs (moments of the data, the start prototypes from rank 0, a barrier, timings) */
+int dbgsom_ctx_allreduce_host(dbgsom_ctx *ctx, double *vals_host, int64_t n);
 
 /* The prototypes resident in HBM (M x d float64; `weights_` of the reference).
  *   set_weights   upload all of them

@@ -232,6 +232,28 @@ def test_bench_under_torchrun_single_rank_rccl():
     assert js["n_gpus"] == 1 and js["value"] > 0 and js["roofline"]["frac"] > 0
 
 
+def test_bench_via_ctx_under_torchrun_without_torch_in_the_workers():
+    """`bench.py --via ctx --gpus 1` launched the way the driver launches the multi-GPU bench: the worker
+    never imports torch, the per-epoch collective is RCCL issued by the library (dbgsom_ctx_set_rccl), the
+    ncclUniqueId travels through a file (DBGSOM_FORCE_COLLECTIVE=1: also for one rank)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DBGSOM_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "2", "--workload", "c2", "--via", "ctx"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    js = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert js["n_gpus"] == 1 and js["value"] > 0 and js["torch_imported"] is False
+    assert "RCCL inside the library" in js["config"]["via"]
+    assert js["exact"]["prototypes_identical_to_headline"] is True
+
+
 def test_bench_two_ranks_strong_scaling_rehearsal_on_one_gpu():
     """The N > 1 path of bench.py (strong scaling: the workload's rows split over the ranks, the
     per-epoch all-reduce, the weak-scaling rate of the same run, one JSON line from rank 0) with two

@@ -318,38 +318,25 @@ def test_ctx_api_bf16_storage_and_allreduce_callback(o):
     del torch
 
 
-def test_ctx_allreduce_seam_with_rccl_through_ctypes():
-    """The multi-GPU route of a NumPy caller: ncclAllReduce plugged into
-    dbgsom_ctx_set_allreduce with ctypes only.  One rank here (a test box has one GPU): the
-    communicator comes up, the collective runs on the context's stream once per epoch, results are
-    the single-rank ones.  Runs in a fresh process so that exactly one HIP runtime is loaded."""
+def test_ctx_rccl_inside_the_library_and_the_callback_seam():
+    """The multi-GPU route of a NumPy caller: RCCL driven by the library itself
+    (dbgsom_rccl_unique_id / dbgsom_rccl_comm_init / dbgsom_ctx_set_rccl: librccl resolved at run time, no
+    callback, no torch) and, for other transports, a callback plugged into dbgsom_ctx_set_allreduce -- here
+    ncclAllReduce on the same communicator through ctypes.  One rank (a test box has one GPU): the
+    communicator comes up, the collective runs on the context's stream once per epoch, results are the
+    single-rank ones either way.  Runs in a fresh process so that exactly one HIP runtime is loaded."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = r'''
-import ctypes, os, sys, importlib.util
+import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, ROOT)
 from dbgsom_amd import _native as nat
 from oracle import som_oracle as o
 nat.load()                                                    # the HIP runtime first (RTLD_GLOBAL)
-tl = os.path.join(os.path.dirname(importlib.util.find_spec("torch").origin), "lib", "librccl.so")
-rccl = ctypes.CDLL(tl if os.path.exists(tl) else "librccl.so")
-class UniqueId(ctypes.Structure):
-    _fields_ = [("internal", ctypes.c_char * 128)]
-uid, comm = UniqueId(), ctypes.c_void_p()
-assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
-rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
-assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
-rccl.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
-                               ctypes.c_void_p, ctypes.c_void_p]
-calls = []
-def allreduce(user, buf, count, stream):                      # ncclDouble = 8, ncclSum = 0
-    calls.append(count)
-    return rccl.ncclAllReduce(buf, buf, count, 8, 0, comm, stream)
-cb = nat.ALLREDUCE_FN(allreduce)
 rng = np.random.default_rng(2)
 N, d, rows, cols = 4000, 40, 12, 12
 M = rows * cols
@@ -361,23 +348,43 @@ ctx = ctypes.c_void_p()
 nat.call("dbgsom_ctx_create", 0, ctypes.byref(ctx))
 nat.call("dbgsom_ctx_load", ctx, X.ctypes.data, nat.F32, N, d, nat.F32)
 nat.call("dbgsom_ctx_set_topology", ctx, hop.ctypes.data, M)
-nat.call("dbgsom_ctx_set_allreduce", ctx, cb, None)
-Wn = np.empty((M, d)); chg = np.empty(1); E = np.empty(M); a = np.empty(M)
-i1 = np.empty(N, np.int64); d1 = np.empty(N)
-nat.call("dbgsom_ctx_epoch", ctx, W.ctypes.data, M, 0, 1e-3, 1.4, nat.CENTRES_COMPACT, 0, Wn.ctypes.data,
-         chg.ctypes.data, E.ctypes.data, a.ctypes.data, i1.ctypes.data, d1.ctypes.data)
+uid, comm = ctypes.create_string_buffer(128), ctypes.c_void_p()
+nat.call("dbgsom_rccl_unique_id", uid)
+nat.call("dbgsom_rccl_comm_init", uid, 1, 0, ctypes.byref(comm))
+assert comm.value
+nat.call("dbgsom_ctx_set_rccl", ctx, comm)
+v = np.arange(5, dtype=np.float64)
+nat.call("dbgsom_ctx_allreduce_host", ctx, v.ctypes.data, v.size)
+assert np.array_equal(v, np.arange(5.0))
 oo = o.epoch(X, W, hop, 1.4, np.float64(1e3), "compact", "chain")
+def epoch():
+    Wn = np.empty((M, d)); chg = np.empty(1); E = np.empty(M); a = np.empty(M)
+    i1 = np.empty(N, np.int64); d1 = np.empty(N)
+    nat.call("dbgsom_ctx_epoch", ctx, W.ctypes.data, M, 0, 1e-3, 1.4, nat.CENTRES_COMPACT, 0, Wn.ctypes.data,
+             chg.ctypes.data, E.ctypes.data, a.ctypes.data, i1.ctypes.data, d1.ctypes.data)
+    assert np.array_equal(i1, oo.winners) and np.array_equal(d1, oo.distances)
+    np.testing.assert_allclose(Wn, oo.new_weights, rtol=1e-11, atol=1e-13)
+    return Wn
+W_lib = epoch()                                               # RCCL issued by the library
+rccl = ctypes.CDLL(os.environ["DBGSOM_RCCL_LIB"])             # (the librccl of the HIP runtime in use)
+rccl.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_void_p, ctypes.c_void_p]
+calls = []
+def allreduce(user, buf, count, stream):                      # ncclDouble = 8, ncclSum = 0
+    calls.append(count)
+    return rccl.ncclAllReduce(buf, buf, count, 8, 0, comm, stream)
+cb = nat.ALLREDUCE_FN(allreduce)
+nat.call("dbgsom_ctx_set_allreduce", ctx, cb, None)           # replaces the library's own
+W_cb = epoch()
 assert calls == [M * (48 + 3) + 1], calls
-assert np.array_equal(i1, oo.winners) and np.array_equal(d1, oo.distances)
-np.testing.assert_allclose(Wn, oo.new_weights, rtol=1e-11, atol=1e-13)
+assert np.array_equal(W_lib, W_cb)
 nat.call("dbgsom_ctx_destroy", ctx)
-rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
-rccl.ncclCommDestroy(comm)
-print("rccl seam ok")
+nat.call("dbgsom_rccl_comm_destroy", comm)
+print("rccl ok")
 '''.replace("ROOT", repr(root))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
-    assert out.returncode == 0 and "rccl seam ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+    assert out.returncode == 0 and "rccl ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 
 
 def test_full_size_properties(hip, o):
