@@ -119,6 +119,7 @@ struct FilteredCall {
     const int64_t *prev_idx = nullptr;
     const int32_t *order = nullptr;
     int seed_stride = 0, sweep_planes = 0, round_f32 = 0;
+    int k = 1;   // nearest prototypes per sample: 1, or 2 (idx / dist then hold N x 2; the pruning form only)
     int64_t *idx = nullptr;
     double *dist = nullptr;
     void *ws = nullptr;

@@ -246,6 +246,7 @@ struct dbgsom_ctx {
     double rf_mean_ref = NAN;
     int rf_measuring = -1;          // the form the running call is timing (-1: none)
     bool last_refined = false;
+    bool last_k2_filtered = false;  // the last k = 2 search went through the pruning form
     int64_t filter_min_query_rows = 32768;
     int64_t max_mean_candidates = 320;
     // samples
@@ -872,6 +873,28 @@ int resident_bmu(dbgsom_ctx *c, const double *W_host, int64_t M, int k, int roun
         return run_filtered(c, s, c->filt_ws, W, M, round_f32, hint ? c->idx[c->icur].as<int64_t>() : nullptr,
                             hint ? c->acc_ws.as<int32_t>() : nullptr, c->qidx.as<int64_t>(), c->qdist.as<double>());
     }
+    // k = 2 (topographic error, BaseSom.py:945): through the pruning form of the filtered search when the
+    // training epochs have shown that it works on this data -- the last filtered search of this map size
+    // ran it (arm 0 of the policy: clustered data, lists a fraction of the map); otherwise all pairs
+    if (k == 2 && filter_applies(c, M) && M <= PRUNE_MAX_M && M >= 2 && c->last_filtered && c->planes_used == 0 &&
+        c->last_filter_M == M && c->last_mean == c->last_mean && c->last_mean <= (double)c->max_mean_candidates) {
+        const bool hint = (c->algorithm == DBGSOM_ALG_AUTO || c->algorithm == DBGSOM_ALG_FILTERED_HINT) &&
+                          c->hint_valid && c->hintM <= M;
+        TRY(ensure_planes(c, s));
+        TRY(c->filt_ws.reserve_zeroed(dbgsom_bmu_filtered_workspace_bytes(s.N, s.dp, M), c->stream));
+        FilteredCall call;
+        call.X = s.Xb; call.x_dtype = s.bdtype; call.N = s.N; call.d = s.dp; call.ldx = s.dp;
+        call.xx = s.xx.as<double>(); call.xplanes = s.planes.p; call.W = W; call.M = M; call.ww = c->ww.as<double>();
+        call.prev_idx = hint ? c->idx[c->icur].as<int64_t>() : nullptr;
+        call.order = hint ? c->acc_ws.as<int32_t>() : nullptr;
+        call.seed_stride = c->seed_stride | DBGSOM_PRUNE | (c->prune_retry && !hint ? DBGSOM_PRUNE_RETRY : 0);
+        call.sweep_planes = 1; call.round_f32 = round_f32; call.k = 2;
+        call.idx = c->qidx.as<int64_t>(); call.dist = c->qdist.as<double>();
+        call.ws = c->filt_ws.p; call.ws_bytes = c->filt_ws.cap; call.stream = c->stream;
+        c->last_k2_filtered = true;
+        return launch_bmu_filtered(call);
+    }
+    c->last_k2_filtered = false;
     return launch_bmu(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), W, M, c->ww.as<double>(), k, round_f32,
                       c->qidx.as<int64_t>(), c->qdist.as<double>(), c->stream);
 }
@@ -980,6 +1003,7 @@ int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
     else if (!strcmp(name, "graph")) *v = c->use_graph;
     else if (!strcmp(name, "refine")) *v = c->refine;
     else if (!strcmp(name, "refined")) *v = c->last_refined ? 1 : 0;
+    else if (!strcmp(name, "k2_filtered")) *v = c->last_k2_filtered ? 1 : 0;
     else if (!strcmp(name, "filter_min_query_rows")) *v = c->filter_min_query_rows;
     else if (!strcmp(name, "max_mean_candidates")) *v = c->max_mean_candidates;
     else if (!strcmp(name, "n_samples")) *v = c->xs.dtype < 0 ? 0 : c->xs.N;

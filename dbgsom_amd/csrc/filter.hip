@@ -1714,7 +1714,10 @@ constexpr double PLANE0_ERR = 32897.0 / (127.0 * 65536.0) * (1.0 + 1e-6);
 // k-tile-major top plane (L2-resident), P = D0 . D0
 __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict__ wt, int w_rows, int dpad, int M, int d,
                                                        const double *__restrict__ tw, const double *__restrict__ wn0,
-                                                       const double *__restrict__ ww, float *__restrict__ gap, int ldg) {
+                                                       const double *__restrict__ ww, float *__restrict__ gap, int ldg,
+                                                       uint32_t *__restrict__ nnub) {
+    // nnub[p] (k = 2 searches; float32 bits, +inf before the launch): an UPPER bound of the distance from
+    // prototype p to its nearest other prototype, from the same products: |w^_p - w^_j| + e_p + e_j
     const int lane = threadIdx.x, lc = lane & 31, lh = lane >> 5;
     const int pb = blockIdx.x * 64, jb = blockIdx.y * 64;
     const int nks = dpad / 32;  // dpad is a multiple of 64
@@ -1782,6 +1785,7 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
         const bool pok = p < M;
         const double tp = pok ? tw[p] : 0.0, Bp = pok ? wn0[p] + 0.0 * ww[p] : 0.0;
         const double ep = root_d * tp * PLANE0_ERR;
+        float near_ub = INFINITY;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -1790,6 +1794,14 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
                 if (!pok || j >= M) continue;
                 const double tj = tj_s[jl], Bj = bj_s[jl], Pv = (double)P[jt][it][r];
                 const double sq = tp * tp * Bp + tj * tj * Bj, cr = 2.0 * tp * tj * Pv;
+                if (nnub && j != p) {
+                    const double uh2 = ((sq - cr) + 1e-12 * (sq + fabs(cr))) * (1.0 / 16129.0) * (1.0 + 1e-12);
+                    // (a NaN -- a row with a NaN or an infinity, whose digits mean nothing -- stays a NaN and never
+                    //  becomes the minimum: no bound from that pair)
+                    const double dh = uh2 > 0.0 ? sqrt(uh2) * (1.0 + 1e-12) : (uh2 == uh2 ? 0.0 : uh2);
+                    const double ub = (dh + (ep + root_d * tj * PLANE0_ERR)) * (1.0 + 1e-6);
+                    if (ub < 3.0e38) near_ub = fminf(near_ub, __double2float_ru(ub));
+                }
                 // (the division by 127^2 as a product by its rounded reciprocal: 2^-53 relative, far
                 //  inside the 1e-12 margins taken just before and after)
                 const double dh2 = ((sq - cr) - 1e-12 * (sq + fabs(cr))) * (1.0 / 16129.0);
@@ -1798,6 +1810,7 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
                 // (anything that is not a positive finite number: no gap known)
                 gap[(size_t)j * ldg + p] = (v > 0.0 && v < 3.0e38) ? __double2float_rz(v) : 0.f;
             }
+        if (nnub && pok && near_ub < INFINITY) atomicMin(&nnub[p], __float_as_uint(near_ub));  // (non-negative floats order like their bits)
     }
 }
 
@@ -1811,7 +1824,10 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
     uint16_t *__restrict__ ulist, int ulist_stride, uint32_t *__restrict__ ucount, uint32_t *__restrict__ sched_ctr,
     unsigned long long *__restrict__ sum_out, int count_only, const double *__restrict__ dist_prev,
     const double *__restrict__ shift, int32_t *__restrict__ retry_groups, unsigned long long *__restrict__ retry_len,
-    int retry_mode, uint32_t retry_above) {
+    int retry_mode, uint32_t retry_above, const uint32_t *__restrict__ nnub) {
+    // nnub != nullptr: the lists of a k = 2 search.  With p2 the seed's nearest other prototype, |x - w_p2| <=
+    // |x - w_p| + nnub[p]: TWO prototypes are at most that far, so everything at least m further cannot be
+    // among the two nearest -- the bound of k = 1 with nnub[p] added to twice the seed distance.
     // retry_mode 1: a workgroup whose list comes out longer than retry_above is not final -- its id goes
     // to retry_groups (its samples' seeds were poor: a cluster none of whose prototypes is in the cheap
     // pre-pass's subset sends its samples to seeds in OTHER clusters, and twice that distance rules
@@ -1923,7 +1939,8 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
                                       ? hint_up[round] + sqrt(rho) * (1.0 + 1e-12)
                                       : (dh2 > 0.0 ? sqrt(dh2) * (1.0 + 1e-12) : 0.0) + root_d * (sv + tv) * PLANE0_ERR;
                 if (fabs(up) < INFINITY) {  // (a NaN fails this too)
-                    const double b = 2.0 * up * (1.0 + 1e-12) + (sqrt(2.0 * rho) * 1.0001 + 1e-300);
+                    const double nn = nnub ? (double)__uint_as_float(nnub[pj]) : 0.0;  // (+inf: no bound, the whole map)
+                    const double b = 2.0 * up * (1.0 + 1e-12) + nn * (1.0 + 1e-12) + (sqrt(2.0 * rho) * 1.0001 + 1e-300);
                     const double b2 = b * b * (1.0 + 1e-12);
                     if (b2 < INFINITY) bits = (unsigned long long)__double_as_longlong(b2);
                 }
@@ -2040,7 +2057,7 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
 // takes the workgroups whose list length falls in its class (<= 16, 17..32, > 32) so that the
 // gathered X tile is streamed once for all but the longest lists (a fourth class of 64 was
 // measured: no gain at C3 / C4, slower at C2).
-template <typename XT, int JTL, int NWV, int SPLIT = 1>
+template <typename XT, int JTL, int NWV, int SPLIT = 1, int K = 1>
 __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
     const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
     const double *__restrict__ W, int M, const double *__restrict__ ww,
@@ -2095,7 +2112,7 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
         isamp[it] = (p < N) ? order[p] : -1;
         xi[it] = (p < N) ? xx[isamp[it]] : 0.0;
     }
-    Best<1> best[IT];
+    Best<K> best[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) best[it].init();
 
@@ -2293,19 +2310,27 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
     for (int it = 0; it < IT; ++it) {
 #pragma unroll
         for (int m = 16; m <= 32; m <<= 1) {
-            double ov[1] = {__shfl_xor(best[it].v[0], m, 64)};
-            int oj[1] = {__shfl_xor(best[it].j[0], m, 64)};
+            double ov[K];
+            int oj[K];
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                ov[u] = __shfl_xor(best[it].v[u], m, 64);
+                oj[u] = __shfl_xor(best[it].j[u], m, 64);
+            }
             best[it].merge(ov, oj);
         }
         if (lq == 0 && isamp[it] >= 0) {
-            double dv = sqrt(best[it].v[0]);
-            if (round_f32) dv = (double)(float)dv;
-            idx_out[isamp[it]] = (best[it].j[0] == 0x7fffffff) ? (int64_t)-1 : (int64_t)best[it].j[0];
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                double dv = sqrt(best[it].v[u]);
+                if (round_f32) dv = (double)(float)dv;
+                idx_out[isamp[it] * K + u] = (best[it].j[u] == 0x7fffffff) ? (int64_t)-1 : (int64_t)best[it].j[u];
 #if SUBSET_EXPERIMENT & 128
-            if (dv == -1.0) dist_out[isamp[it]] = dv;
+                if (dv == -1.0) dist_out[isamp[it] * K + u] = dv;
 #else
-            dist_out[isamp[it]] = dv;
+                dist_out[isamp[it] * K + u] = dv;
 #endif
+            }
         }
     }
 #if SUBSET_EXPERIMENT & 128
@@ -2358,6 +2383,7 @@ struct FilterWs {
     int32_t *order;    // N   bucket order of the samples by seed
     float *gap;        // Mg x Mg lower bounds of the squared distances between prototypes (2c); M <= PRUNE_MAX_M
     int32_t *retry;    // nb: workgroups of the pruning form to be re-seeded
+    uint32_t *nnub;    // Mg float32 bit patterns: upper bounds of the prototypes' nearest-neighbour distances (k = 2)
     unsigned long long *cand;  // N: per-sample candidates (four prototype ids) after the refinement (2d)
     int64_t *rbest;    // N: the refinement's best prototype per sample (bucket key of the pair kernel)
     int32_t *order2;   // N: the samples bucketed by it
@@ -2394,8 +2420,10 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const int64_t Mg = (M + 63) / 64 * 64;
     const size_t o20 = take(M <= PRUNE_MAX_M ? (size_t)Mg * Mg * 4 : 0);
     const size_t o21 = take((size_t)nb * 4);
+    const size_t o28 = take((size_t)Mg * 4);
     if (f) {
         f->retry = (int32_t *)(base + o21);
+        f->nnub = (uint32_t *)(base + o28);
         f->cand = (unsigned long long *)(base + o22); f->gflag = (uint8_t *)(base + o23);
         f->rbest = (int64_t *)(base + o25); f->order2 = (int32_t *)(base + o26); f->ovf = (int32_t *)(base + o27);
         f->rf_ctr = (unsigned long long *)(base + o17 + (size_t)SCHED_CTR * 4);
@@ -2590,6 +2618,11 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
     // DBGSOM_PRUNE_RETRY (stateless searches with cheap seeds): workgroups whose pruned lists come out
     // long are re-seeded against every prototype and pruned again (two more short launches)
     const bool prune_retry = (seed_stride & DBGSOM_PRUNE_RETRY) != 0 && !seed_full && !prev_idx_dev;
+    // k = 2 (the two nearest prototypes: topographic error, BaseSom.py:945): the pruning form only
+    const bool k2 = call.k == 2;
+    DBGSOM_REQUIRE(call.k == 1 || call.k == 2, "k must be 1 or 2");
+    DBGSOM_REQUIRE(!k2 || (prune && call.refine_rows == 0 && M >= 2),
+                   "k = 2 needs the pruning form (DBGSOM_PRUNE, M <= 8192) without the refinement");
     seed_stride &= ~(DBGSOM_PRUNE | DBGSOM_PRUNE_PROBE | DBGSOM_PRUNE_RETRY);
     seed_stride = seed_full ? 1 : seed_stride;
     DBGSOM_REQUIRE(seed_stride >= 0 && seed_stride <= 64, "seed_stride outside [0, 64]");
@@ -2691,8 +2724,9 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
                        f.ucount, (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr, f.sched_ctr)
     if (prune || prune_probe) {
         const unsigned gt = (unsigned)(f.Mg / 64);
+        if (k2) DBGSOM_HIP_CHECK(hipMemsetAsync(f.nnub, 0x7f, (size_t)f.Mg * 4, s));   // (0x7f7f7f7f: 3.4e38, "no bound")
         hipLaunchKernelGGL(proto_gap_kernel, dim3(gt, gt), dim3(64), 0, s, f.wt, (int)f.Mpad, dpad, (int)M, (int)d,
-                           f.wscale, f.wn0, ww_dev, f.gap, (int)f.Mg);
+                           f.wscale, f.wn0, ww_dev, f.gap, (int)f.Mg, k2 ? f.nnub : (uint32_t *)nullptr);
         unsigned long long *sum = reinterpret_cast<unsigned long long *>(f.sched_ctr + SCHED_SUM) + (prune ? 0 : 1);
         unsigned long long *rlen = reinterpret_cast<unsigned long long *>(f.sched_ctr + SCHED_RETRY);
         const uint32_t retry_above = (uint32_t)(M / 8 > 96 ? M / 8 : 96);
@@ -2701,7 +2735,7 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
                            N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, ww_dev, f.summary, (int)M, prev_idx_dev,
                            order_dev, f.gap, (int)f.Mg, f.ulist, (int)f.Mpad, f.ucount, f.sched_ctr, sum,
                            prune ? 0 : 1, g_hint_shift ? g_hint_dist : (const double *)nullptr, g_hint_shift,
-                           f.retry, rlen, prune_retry ? 1 : 0, retry_above);
+                           f.retry, rlen, prune_retry ? 1 : 0, retry_above, k2 ? f.nnub : (const uint32_t *)nullptr);
         if (prune_retry) {
             // every prototype, every feature, one digit product, for the listed workgroups only
             S4_LAUNCH(1, f.nb, xb.planes, xb.scale, xb.l1, xx_dev, N, (int)d, dpad, f.wt,
@@ -2711,7 +2745,8 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
             hipLaunchKernelGGL(prune_mark_kernel, dim3((unsigned)f.nb), dim3(256), 0, s, xb.planes, xb.scale, xx_dev,
                                N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, ww_dev, f.summary, (int)M, prev_idx_dev,
                                order_dev, f.gap, (int)f.Mg, f.ulist, (int)f.Mpad, f.ucount, f.sched_ctr, sum,
-                               prune ? 0 : 1, (const double *)nullptr, (const double *)nullptr, f.retry, rlen, 2, retry_above);
+                               prune ? 0 : 1, (const double *)nullptr, (const double *)nullptr, f.retry, rlen, 2, retry_above,
+                               k2 ? f.nnub : (const uint32_t *)nullptr);
         }
     }
     // one digit product: 4-wavefront workgroups unless DBGSOM_SWEEP_SHAPE=8 (see dbgsom_sweep_shape)
@@ -2859,9 +2894,27 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         if (w_ == 8) DBGSOM_SUBSET_W(JTL, 8, STREAM);                                             \
         else DBGSOM_SUBSET_W(JTL, 4, STREAM);                                                     \
     } while (0)
-    DBGSOM_SUBSET(3, s_mfma);
-    DBGSOM_SUBSET(2, refine ? s3 : s2);
-    DBGSOM_SUBSET(1, s3);
+    if (k2) {
+#define DBGSOM_SUBSET_K2(JTL, STREAM)                                                             \
+    do {                                                                                          \
+        if (x_dtype == DBGSOM_F32)                                                                \
+            hipLaunchKernelGGL((subset_exact_kernel<float, JTL, 4, 1, 2>), dim3((unsigned)f.nb), dim3(256), 0, STREAM, \
+                               (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
+                               order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
+        else                                                                                      \
+            hipLaunchKernelGGL((subset_exact_kernel<double, JTL, 4, 1, 2>), dim3((unsigned)f.nb), dim3(256), 0, STREAM, \
+                               (const double *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
+                               order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
+    } while (0)
+        DBGSOM_SUBSET_K2(3, s_mfma);
+        DBGSOM_SUBSET_K2(2, s2);
+        DBGSOM_SUBSET_K2(1, s3);
+#undef DBGSOM_SUBSET_K2
+    } else {
+        DBGSOM_SUBSET(3, s_mfma);
+        DBGSOM_SUBSET(2, refine ? s3 : s2);
+        DBGSOM_SUBSET(1, s3);
+    }
 #undef DBGSOM_SUBSET
 #undef DBGSOM_SUBSET_W
 #undef DBGSOM_SWEEP

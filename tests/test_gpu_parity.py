@@ -1222,3 +1222,61 @@ def test_refinement_is_chosen_by_measurement():
     assert True in seen[1:] and False in seen[1:], (seen, fi.filter_log)   # both forms were timed
     assert len(set(seen[-3:])) == 1, (seen, fi.filter_log)    # settled
     fi.release()
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "bf16"])
+def test_two_nearest_prototypes_through_the_pruning_form(o, dt):
+    """k = 2 (topographic error, BaseSom.py:924-953; Delaunay edges, :987) through the filtered search:
+    with p2 the seed's nearest other prototype, two prototypes are within |x - w_p| + |w_p - w_p2| of the
+    sample, so the pruning bound of k = 1 plus an upper bound of |w_p - w_p2| keeps everything that can be
+    among the two nearest; the exact stage keeps (best, second).  Taken when the training epochs ran the
+    pruning form; results are the all-pairs kernel's and the oracle's bit for bit -- ties, duplicated
+    prototypes and a NaN row included -- and so is the topographic count."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(23)
+    N, d, rows, cols = 30_000, 200, 18, 20
+    M = rows * cols
+    hop = gi.lattice_hops(rows, cols)
+    X, _ = gi.blobs_f32(N, d, 55)
+    X = X.astype(np.float64) if dt == "f64" else X
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    W[7] = W[3]                                   # duplicates: (best, second) = (3, 7) for their samples
+    W[100:104] = W[99]
+    storage = "bf16" if dt == "bf16" else None
+    ex = HipBackend(algorithm="exact").load(X, storage=storage)
+    fi = HipBackend(algorithm="filtered").load(X, storage=storage)
+    fi.sweep_planes = 4
+    coords = np.stack(np.divmod(np.arange(M), cols), axis=1)
+    Xr = X
+    if dt == "bf16":
+        import torch
+        Xr = torch.from_numpy(X).to(torch.bfloat16).float().numpy()
+    for e in range(3):
+        fi.epoch(W, hop, 0.8, 1e-3, "aligned", True)           # (the pruning form ran: k = 2 may follow it)
+        Wn = W.copy()
+        if e == 2:
+            Wn[150] = np.nan                                    # a dead neuron of the aligned layout
+        de, ie = ex.bmu(Wn, 2)
+        df, i_f = fi.bmu(Wn, 2)
+        assert fi._get("k2_filtered") == 1, (e, fi.epoch_info(), fi._get("planes_used"))
+        assert np.array_equal(i_f, ie) and np.array_equal(df, de)
+        pick = rng.choice(N, 1000, replace=False)
+        rd, ri = o.bmu_chain(Xr[pick], Wn, 2)
+        assert np.array_equal(i_f[pick], ri) and np.array_equal(df[pick], rd)
+        assert fi.topographic_error_count(Wn, coords) == ex.topographic_error_count(Wn, coords)
+        fi.algorithm = "filtered_hint"                          # seeds = the epoch's winners from now on
+        W = W + rng.normal(size=W.shape) * 0.05                 # the map moves a little between epochs
+        W[7] = W[3]
+        W[100:104] = W[99]
+    # data without clusters: the policy keeps a sweep, k = 2 stays with the all-pairs kernel
+    Xi = rng.normal(size=(8000, 64)).astype(np.float32)
+    Wi = Xi[rng.choice(8000, 300, replace=False)].astype(np.float64)
+    fi2 = HipBackend(algorithm="filtered").load(Xi)
+    ex2 = HipBackend(algorithm="exact").load(Xi)
+    fi2.epoch(Wi, np.zeros((300, 300)), 1.0, 1e-2, "aligned", True)
+    d2, i2 = fi2.bmu(Wi, 2)
+    de2, ie2 = ex2.bmu(Wi, 2)
+    assert np.array_equal(i2, ie2) and np.array_equal(d2, de2)
+    for b in (ex, fi, fi2, ex2):
+        b.release()
