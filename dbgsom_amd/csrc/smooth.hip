@@ -8,14 +8,20 @@
 // The reference materialises an (M, M, d) float64 temporary for the same sum; here it is one
 // M x M x d float64 GEMM (2 M^2 d flops, < 0.2 % of the BMU work at M ~ 1000), LDS-tiled.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
 namespace dbgsom {
 
+// G and C are stored for the GEMM's LDS-DMA tiles: G with a leading dimension of Mp = M rounded up to 16
+// (zeros behind column M), C with Mp rows (zero rows behind row M) and one tile of slack behind it -- a
+// k-tile is then always whole, zeros add nothing to an fma chain, and no tile read leaves the buffers.
+static inline int64_t smooth_mp(int64_t M) { return (M + 15) / 16 * 16; }
+
 struct SmoothWs {
-    double *C;      // M x d   Voronoi centres in the requested layout
-    double *G;      // M x M   h * a^T
+    double *C;      // Mp x d  Voronoi centres in the requested layout
+    double *G;      // M x Mp  h * a^T
     double *den;    // M
     double *rowchg; // M
     uint32_t *ticket;  // "last workgroup" ticket of the row-change kernel
@@ -37,7 +43,8 @@ static int gemm_splits(int64_t M, int64_t d) {
 static size_t carve_smooth(SmoothWs *w, char *base, int64_t M, int64_t d) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
-    const size_t oC = take((size_t)M * d * 8), oG = take((size_t)M * M * 8);
+    const int64_t Mp = smooth_mp(M);
+    const size_t oC = take(((size_t)Mp * d + 64) * 8), oG = take(((size_t)M * Mp + 16) * 8);
     const size_t oD = take((size_t)M * 8), oR = take((size_t)M * 8), oK = take((size_t)M * 4);
     const int ks = gemm_splits(M, d);
     const size_t oP = take(ks > 1 ? (size_t)ks * M * d * 8 : 0);
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void smooth_prep_kernel(const double *__restri
                                                           int layout, double two_sigma_sq,
                                                           double *__restrict__ C, double *__restrict__ G,
                                                           double *__restrict__ den,
-                                                          uint32_t *__restrict__ ticket) {
+                                                          uint32_t *__restrict__ ticket, int Mp) {
     __shared__ double red[256];
     __shared__ int cnt[256], cnt_all[256];
     const int i = blockIdx.x, t = threadIdx.x;
@@ -98,12 +105,17 @@ __global__ __launch_bounds__(256) void smooth_prep_kernel(const double *__restri
     const bool zero_row = (layout == DBGSOM_CENTRES_COMPACT) ? (i >= nne) : !alive;
     if (zero_row)
         for (int c = t; c < d; c += 256) C[(size_t)i * d + c] = 0.0;
+    if (i == 0)  // (the zero rows of C behind row M)
+        for (int e = t; e < (Mp - M) * d; e += 256) C[(size_t)M * d + e] = 0.0;
     double s = 0.0;
-    for (int j = t; j < M; j += 256) {
-        const double h = (double)hop[(size_t)i * M + j];
-        const double g = exp(-((h * h) / two_sigma_sq)) * a[j];
-        G[(size_t)i * M + j] = g;
-        s += g;
+    for (int j = t; j < Mp; j += 256) {
+        double g = 0.0;
+        if (j < M) {
+            const double h = (double)hop[(size_t)i * M + j];
+            g = exp(-((h * h) / two_sigma_sq)) * a[j];
+            s += g;
+        }
+        G[(size_t)i * Mp + j] = g;
     }
     red[t] = s;
     __syncthreads();
@@ -114,14 +126,141 @@ __global__ __launch_bounds__(256) void smooth_prep_kernel(const double *__restri
     if (t == 0) den[i] = red[0];
 }
 
-// W'[i, c] = (sum_j G[i, j] C[j, c]) / den[i] on the f64 matrix cores: 64 x 64 tile per
-// workgroup, 4 wavefronts of 2 x 2 v_mfma_f64_16x16x4_f64 tiles, j ascending inside one
-// accumulator chain (sequential like the reference's np.sum over axis 1)
+// W'[i, c] = (sum_j G[i, j] C[j, c]) / den[i] on the f64 matrix cores: 64 x 64 tile per workgroup, 4
+// wavefronts of 2 x 2 v_mfma_f64_16x16x4_f64 tiles, j ascending inside one accumulator chain (sequential
+// like the reference's np.sum over axis 1).  Operand tiles (64 rows of G x 16 j, 16 rows of C x 64 columns:
+// 8 KB each) come through a 3-stage LDS-DMA ring -- global_load_lds_dwordx4, counted s_waitcnt vmcnt, ONE
+// raw barrier per k-tile -- the ring of bmu_dma_kernel (0.85 of the f64 matrix peak on the same kind of
+// product; the register-staged tiles with two barriers per k-tile this replaces reached 0.57).  The
+// accumulation order is unchanged: results are the former kernel's bit for bit.
 typedef double sd4_t __attribute__((ext_vector_type(4)));
-constexpr int GT = 64, GK = 16, GS_A = GK + 2, GS_B = GT + 16;
-__global__ __launch_bounds__(256) void smooth_gemm_kernel(const double *__restrict__ G,
+typedef __attribute__((address_space(3))) void *sm_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *sm_gbl_ptr_t;
+__device__ __forceinline__ void sm_dma16(const void *src, void *lds_dst) {
+    __builtin_amdgcn_global_load_lds((sm_gbl_ptr_t)src, (sm_lds_ptr_t)lds_dst, 16, 0, 0);
+}
+constexpr int GT = 64, GK = 16;
+constexpr int GR = 128;   // rows of G per workgroup of the DMA kernel (columns: GT)
+constexpr int SG_A = GR * GK * 8, SG_B = GK * GT * 8, SG_STAGE = SG_A + SG_B;   // 16 + 8 KB
+__global__ __launch_bounds__(256, 2) void smooth_gemm_kernel(const double *__restrict__ G,
+                                                             const double *__restrict__ C,
+                                                             const double *__restrict__ den, int M, int Mp,
+                                                             int d, int splits,
+                                                             double *__restrict__ part,
+                                                             double *__restrict__ Wn) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * SG_STAGE];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 wavefronts, 64 rows x 32 columns each (4 x 2 matrix tiles)
+    const int lr = lane & 15, lq = lane >> 4;
+    const int i0 = blockIdx.y * GR, c0 = blockIdx.x * GT;
+    // this workgroup's piece of the k range (whole k-tiles)
+    const int per = ((M + GK - 1) / GK + splits - 1) / splits * GK;
+    const int jlo = blockIdx.z * per, jhi = min(Mp, jlo + per);
+    const int ntile = jhi > jlo ? (jhi - jlo) / GK : 0;
+    // DMA sources.  A tile: 128 rows x 128 bytes, 8 rows per instruction, wavefront w issues rows 32 w .. 32 w +
+    // 31 (four instructions); LDS chunk cp of row r holds the row's 16-byte chunk cp ^ ((r >> 1) & 7).
+    // B tile: 16 rows x 512 bytes, 2 rows per instruction, wavefront w issues rows 4 w .. 4 w + 3; LDS chunk
+    // cp of row j holds chunk cp ^ ((j & 1) << 3): the two j of a read group hit different bank halves.
+    const double *asrc[4], *bsrc[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = 32 * wave + 8 * u + (lane >> 3), cp = lane & 7;
+        int gi = i0 + r;
+        gi = gi < M ? gi : M - 1;   // (rows behind M: any row will do, the results are not stored)
+        asrc[u] = G + (size_t)gi * Mp + ((cp ^ ((r >> 1) & 7)) << 1);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = 4 * wave + 2 * u + (lane >> 5), cq = lane & 31;
+        bsrc[u] = C + (size_t)j * d + c0 + ((cq ^ ((j & 1) << 3)) << 1);   // (columns behind d: the slack, not stored)
+    }
+    int i_t = 0, i_stage = 0;
+    auto issue = [&]() {
+        char *stage = smem + i_stage;
+        const int j0 = jlo + i_t * GK;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sm_dma16(asrc[u] + j0, stage + 1024 * (4 * wave + u));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) sm_dma16(bsrc[u] + (size_t)j0 * d, stage + SG_A + 1024 * (2 * wave + u));
+        i_stage = (i_stage == 2 * SG_STAGE) ? 0 : i_stage + SG_STAGE;
+        ++i_t;
+    };
+    int a_off[4], a_swz[4], b_off[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ra = wr * 64 + u * 16 + lr;
+        a_off[u] = ra * 128 + (lq & 1) * 8;
+        a_swz[u] = (ra >> 1) & 7;
+    }
+#pragma unroll
+    for (int v = 0; v < 2; ++v) b_off[v] = (wc * 32 + v * 16 + lr) * 8;   // byte offset of the column in a 512-byte row
+    sd4_t acc[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[u][v] = sd4_t{0.0, 0.0, 0.0, 0.0};
+    if (ntile > 0) issue();
+    if (ntile > 1) issue();
+    int r_stage = 0;
+    for (int tl = 0; tl < ntile; ++tl) {
+        if (tl + 1 < ntile) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char *stage = smem + r_stage;
+        r_stage = (r_stage == 2 * SG_STAGE) ? 0 : r_stage + SG_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < GK / 4; ++ks) {
+            // (the DMAs of tile tl + 2 go out behind the first eight matrix instructions: an LDS-DMA holds the
+            //  wavefront's issue for ~100 cycles, which the matrix pipe then covers)
+            if (ks == 1 && tl + 2 < ntile) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            double a[4], b[2];
+            const int jr = 4 * ks + lq;   // row of the B tile
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ca = (2 * ks + (lq >> 1)) ^ a_swz[u];
+                a[u] = *reinterpret_cast<const double *>(stage + a_off[u] + ca * 16);
+            }
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+                b[v] = *reinterpret_cast<const double *>(stage + SG_A + jr * 512 + (b_off[v] ^ ((jr & 1) << 7)));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v)
+                    acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
+        }
+    }
+    // D layout: reg r of lane l = D[row = (l >> 4) + 4 r][col = l & 15]
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + wr * 64 + u * 16 + lq + 4 * r;
+            if (i >= M) continue;
+            const double dn = den[i];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int c = c0 + wc * 32 + v * 16 + lr;
+                if (c >= d) continue;
+                if (splits == 1) Wn[(size_t)i * d + c] = acc[u][v][r] / dn;
+                else part[((size_t)blockIdx.z * M + i) * d + c] = acc[u][v][r];
+            }
+        }
+}
+
+// The same product with register-staged tiles (two barriers per k-tile): rows of C that are not 16-byte
+// multiples (odd d through the device-level ABI) cannot be the source of an LDS-DMA.  Same accumulation
+// order, same results.
+constexpr int GS_A = GK + 2, GS_B = GT + 16;
+__global__ __launch_bounds__(256) void smooth_gemm_generic_kernel(const double *__restrict__ G,
                                                           const double *__restrict__ C,
-                                                          const double *__restrict__ den, int M,
+                                                          const double *__restrict__ den, int M, int Mp,
                                                           int d, int splits,
                                                           double *__restrict__ part,
                                                           double *__restrict__ Wn) {
@@ -150,7 +289,7 @@ __global__ __launch_bounds__(256) void smooth_gemm_kernel(const double *__restri
             const int e = t + 256 * u;
             const int r = e / GK, k = e % GK;  // G tile: 64 rows x 16 j
             const int gi = i0 + r, gj = j0 + k;
-            gr[u] = (gi < M && gj < jhi) ? G[(size_t)gi * M + gj] : 0.0;
+            gr[u] = (gi < M && gj < jhi) ? G[(size_t)gi * Mp + gj] : 0.0;
             const int kr = e / GT, cc = e % GT;  // C tile: 16 j x 64 cols
             const int cj = j0 + kr, col = c0 + cc;
             cr[u] = (cj < jhi && col < d) ? C[(size_t)cj * d + col] : 0.0;
@@ -272,12 +411,21 @@ int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, do
     carve_smooth(&w, (char *)ws, M, d);
     const int Mi = (int)M, di = (int)d;
     const double *S = sums, *K = sums + (size_t)M * d, *a = K + M;
+    const int Mp = (int)smooth_mp(M);
     hipLaunchKernelGGL(smooth_prep_kernel, dim3((unsigned)M), dim3(256), 0, s, S, K, a, hop, Mi, di, layout,
-                       2.0 * (sigma * sigma), w.C, w.G, w.den, w.ticket);
+                       2.0 * (sigma * sigma), w.C, w.G, w.den, w.ticket, Mp);
     const int splits = gemm_splits(M, d);
     dim3 grid((unsigned)((d + GT - 1) / GT), (unsigned)((M + GT - 1) / GT), (unsigned)splits);
-    hipLaunchKernelGGL(smooth_gemm_kernel, grid, dim3(256), 0, s, w.G, w.C, w.den, Mi, di, splits,
-                       w.part, W_new);
+    static const bool force_generic = [] {   // DBGSOM_SMOOTH_GENERIC=1: the register-staged kernel everywhere (tests)
+        const char *e = getenv("DBGSOM_SMOOTH_GENERIC");
+        return e && atoi(e) != 0;
+    }();
+    if (d % 2 == 0 && !force_generic)
+        hipLaunchKernelGGL(smooth_gemm_kernel, dim3((unsigned)((d + GT - 1) / GT), (unsigned)((M + GR - 1) / GR), (unsigned)splits), dim3(256), 0, s, w.G, w.C, w.den, Mi, Mp, di, splits,
+                           w.part, W_new);
+    else
+        hipLaunchKernelGGL(smooth_gemm_generic_kernel, grid, dim3(256), 0, s, w.G, w.C, w.den, Mi, Mp, di, splits,
+                           w.part, W_new);
     hipLaunchKernelGGL(rowchange_kernel, dim3((unsigned)M), dim3(256), 0, s, W_old, W_new, Mi, di,
                        splits, w.part, w.den, w.rowchg, w.ticket, change_total);
     return launch_status("smooth kernels");

@@ -1280,3 +1280,45 @@ def test_two_nearest_prototypes_through_the_pruning_form(o, dt):
     assert np.array_equal(i2, ie2) and np.array_equal(d2, de2)
     for b in (ex, fi, fi2, ex2):
         b.release()
+
+
+def test_smoothing_gemm_on_the_dma_ring_is_the_register_staged_one_bit_for_bit(o):
+    """dbgsom_smooth: the LDS-DMA-ring GEMM against the register-staged kernel it replaced (same j-ascending
+    accumulation chains, same split-K pieces): identical W' and change_total, bit for bit, for map sizes
+    that are no multiples of the tiles, with and without split-K, and against the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, ROOT)
+from dbgsom_amd.backend import HipBackend
+rng = np.random.default_rng(4)
+out = {}
+for (N, d, M) in [(3000, 48, 130), (3000, 784, 1024), (2000, 100, 77), (2500, 2048, 4096), (1500, 64, 2025), (900, 16, 17)]:
+    X = (rng.normal(size=(N, d)) + 2 * rng.integers(0, 6, size=(N, 1))).astype(np.float32)
+    W = X[rng.choice(N, M, replace=M > N)].astype(np.float64) + rng.normal(size=(M, d)) * 1e-2
+    r, c = np.divmod(np.arange(M), int(np.ceil(np.sqrt(M))))
+    hop = (np.abs(r[:, None] - r[None]) + np.abs(c[:, None] - c[None])).astype(np.float64)
+    be = HipBackend(algorithm="exact").load(X)
+    res = be.epoch(W, hop, 1.7, 1e-3, "compact", True)
+    out[(N, d, M)] = (res.new_weights, res.change_total)
+    be.release()
+np.savez(sys.argv[1], **{f"{k[0]}_{k[1]}_{k[2]}_W": v[0] for k, v in out.items()},
+         **{f"{k[0]}_{k[1]}_{k[2]}_c": v[1] for k, v in out.items()})
+'''.replace("ROOT", repr(root))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        files = {}
+        for tag, env_val in (("dma", "0"), ("generic", "1")):
+            files[tag] = os.path.join(td, tag + ".npz")
+            env = dict(os.environ, DBGSOM_SMOOTH_GENERIC=env_val)
+            out = subprocess.run([sys.executable, "-c", code, files[tag]], capture_output=True, text=True,
+                                 timeout=600, env=env)
+            assert out.returncode == 0, out.stderr[-3000:]
+        a, b = np.load(files["dma"]), np.load(files["generic"])
+        assert sorted(a.files) == sorted(b.files) and len(a.files) == 12
+        for k in a.files:
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
