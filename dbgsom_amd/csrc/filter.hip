@@ -57,10 +57,11 @@ constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
 // plane rows are padded to whole k-tiles, at least two of them (the sweep's ring runs three tiles
 // ahead and keeps three chunk tables)
 inline int64_t filter_dpad(int64_t d) {
-    // (whole 128-byte lines per row: with 64-byte pitches every second row starts in the middle of a line
-    //  and a pass over gathered rows fetches 1.5 x the plane -- measured on prune_mark_kernel at d = 784)
-    const int64_t p = (d + 2 * FKT - 1) / (2 * FKT) * (2 * FKT);
-    return p;
+    // (a 128-byte pitch -- whole cache lines per row -- was measured in round 3: prune_mark_kernel fetched
+    //  the same 1.25 GB at d = 784 either way, and the seventh part more plane cost the pre-pass and the
+    //  pruning pass 8 % each)
+    const int64_t p = (d + FKT - 1) / FKT * FKT;
+    return p < 2 * FKT ? 2 * FKT : p;
 }
 
 // ---- 1. digit planes --------------------------------------------------------------------------
@@ -2817,21 +2818,26 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         }
         // every launch is a few workgroups per CU walking its class's queue
 #define DBGSOM_REFINE_LAUNCH(NJ_, JT_, CLS, WGS)                                                                  \
-    hipLaunchKernelGGL((refine_i8_kernel<NJ_, JT_>), dim3((unsigned)(f.nb < (WGS) ? f.nb : (WGS))), dim3(NJ_ * 256), 0, s, \
+    hipLaunchKernelGGL((refine_i8_kernel<NJ_, JT_>), dim3((unsigned)((f.nb + 7) / 8 * 8 < (WGS) ? (f.nb + 7) / 8 * 8 : (WGS))), dim3(NJ_ * 256), 0, s, \
                        xb.planes, xb.scale, xb.res16, xx_dev, N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, ww_dev,    \
                        f.summary, order_dev, f.ulist, (int)f.Mpad, f.ucount, f.rf_queue + (size_t)(CLS) * f.nb,      \
                        f.rf_qlen + (CLS), f.cand, f.rbest, f.rf_ctr, f.ovf, f.rf_qlen + 2)
-        if (rows0 == 32) DBGSOM_REFINE_LAUNCH(1, 1, 0, 1024);
-        else if (rows0 == 64) DBGSOM_REFINE_LAUNCH(1, 2, 0, 1024);
-        else if (rows0 == 128) DBGSOM_REFINE_LAUNCH(2, 2, 0, 512);
-        DBGSOM_REFINE_LAUNCH(2, 4, 1, 512);
+        static const int wgs_env = [] {   // DBGSOM_REFINE_WGS: workgroups per launch (diagnostics; a multiple of 8)
+            const char *e = getenv("DBGSOM_REFINE_WGS");
+            return e ? atoi(e) / 8 * 8 : 0;
+        }();
+        const int wgs1 = wgs_env >= 8 ? wgs_env : 1024, wgs2 = wgs_env >= 8 ? wgs_env : 512;
+        if (rows0 == 32) DBGSOM_REFINE_LAUNCH(1, 1, 0, wgs1);
+        else if (rows0 == 64) DBGSOM_REFINE_LAUNCH(1, 2, 0, wgs1);
+        else if (rows0 == 128) DBGSOM_REFINE_LAUNCH(2, 2, 0, wgs2);
+        DBGSOM_REFINE_LAUNCH(2, 4, 1, wgs2);
 #undef DBGSOM_REFINE_LAUNCH
         // the samples by their refined best prototype: a workgroup of the pair kernel then shares its candidates
         const int rc = launch_bucket_sort(f.rbest, N, M, f.order2, f.sort_ws, s);
         if (rc != DBGSOM_OK) return rc;
         // (bfloat16-resident samples: the pair kernel reads the stored rows -- half the bytes of the widened
         //  copy the matrix kernels use, the same values)
-        const unsigned pgrid = (unsigned)((N + PS - 1) / PS);
+        const unsigned pgrid = (unsigned)(((N + PS - 1) / PS + 7) / 8 * 8);   // (whole rounds of the 8 XCDs: xcd_group)
         if (call.X_store && call.store_dtype == DBGSOM_BF16 && x_dtype == DBGSOM_F32)
             hipLaunchKernelGGL((pair_exact_kernel<bf16_t, 32, 128>), dim3(pgrid), dim3(256), 0, s, (const bf16_t *)call.X_store, N,
                                (int)d, call.ld_store, xx_dev, W_dev, ww_dev, f.order2, f.cand, round_f32, idx_dev, dist_dev, f.rf_ctr);

@@ -36,6 +36,12 @@ constexpr int RF_MAX_PAIRS = 512;     // pairs per 128-sample workgroup of the p
 constexpr int RF_HASH = 512;          // slots of its table of distinct candidates
 constexpr unsigned long long RF_NONE = 0xffffffffffffffffull;  // four empty slots (prototype ids are < 0xffff)
 
+// Workgroups are dealt to the 8 XCDs round robin (b % 8), each XCD with an L2 of its own.  Neighbouring
+// 128- / 64-sample workgroups share their prototypes (samples arrive bucketed): give every XCD a contiguous
+// eighth of them, so that a prototype tile is fetched into ONE L2 instead of eight.  Bijective on a grid
+// that is a multiple of 8; the order only decides who runs where.
+__device__ __forceinline__ int xcd_group(int b, int n_groups8) { return (b & 7) * (n_groups8 >> 3) + (b >> 3); }
+
 template <int NJ, int JT>
 struct RefineCfg {
     static constexpr int NW = 4 * NJ;          // wavefronts: 4 (32 samples each) x NJ (parts of the list)
@@ -75,8 +81,12 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     const int wi = wave & 3, wj = wave >> 2;
     const int lc = lane & 31, lh = lane >> 5;
     const int qn = (int)*queue_len;
-    for (int entry = blockIdx.x; entry < qn; entry += gridDim.x) {
-    if (entry != (int)blockIdx.x) __syncthreads();  // the previous workgroup's tables are done with
+    // (XCD x = blockIdx % 8 walks the x-th eighth of the queue, gridDim / 8 workgroups side by side)
+    const int per_xcd = (qn + 7) / 8, q_lo = (int)(blockIdx.x & 7) * per_xcd, q_hi = min(qn, q_lo + per_xcd);
+    const int q_first = q_lo + (int)(blockIdx.x >> 3), q_step = (int)(gridDim.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= q_step) return;  // (a grid that is no multiple of 8: the odd workgroups have no part)
+    for (int entry = q_first; entry < q_hi; entry += q_step) {
+    if (entry != q_first) __syncthreads();  // the previous workgroup's tables are done with
     const int group = queue[entry];
     const int64_t p0 = (int64_t)group * 128;
     const int cnt_all = __builtin_amdgcn_readfirstlane((int)ucount[group]);  // 1 <= cnt_all <= RF_SEGS ROWS (class_fill_kernel)
@@ -420,7 +430,8 @@ __global__ __launch_bounds__(256, 2) void pair_exact_kernel(
     uint8_t *psamp = reinterpret_cast<uint8_t *>(smem + O_PSAMP);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t p0 = (int64_t)blockIdx.x * PS;
+    const int64_t p0 = (int64_t)xcd_group((int)blockIdx.x, (int)gridDim.x) * PS;
+    if (p0 >= N) return;
 
     // ---- pairs and the distinct candidates --------------------------------------------------------
     for (int h = tid; h < RF_HASH; h += 256) table[h] = 0xffffffffu;

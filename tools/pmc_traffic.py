@@ -22,7 +22,8 @@ import bench  # noqa: E402
 
 KEYS = {"sweep": "sweep4_i8_kernel<0", "prepass": "sweep4_i8_kernel<1", "subset_exact": "subset_exact_kernel",
         "segsum": "segsum_kernel", "bmu_dma": "bmu_dma_kernel", "smooth_gemm": "smooth_gemm_kernel",
-        "prune": "prune_mark_kernel", "proto_gap": "proto_gap_kernel"}
+        "prune": "prune_mark_kernel", "proto_gap": "proto_gap_kernel", "refine": "refine_i8_kernel",
+        "pair_exact": "pair_exact_kernel"}
 
 
 def per_kernel(root, counter):
@@ -37,7 +38,7 @@ def per_kernel(root, counter):
 def main():
     workload, fdir, wdir = sys.argv[1], sys.argv[2], sys.argv[3]
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
-    entry = {"source": f"profiles/r02_{workload}_pmc_traffic.txt"}
+    entry = {"source": f"profiles/r03_{workload}_pmc_traffic.txt"}
     lines = [f"# workload {workload}, build {bench.source_hash()}: HBM bytes per launch = FETCH_SIZE KiB x 1024 x 2 "
              f"(gfx950 correction) + WRITE_SIZE KiB x 1024"]
     total = 0.0
@@ -56,7 +57,7 @@ def main():
     table = json.load(open(path)) if os.path.exists(path) else {}
     table.setdefault(bench.source_hash(), {})[workload] = entry
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
-    open(os.path.join(ROOT, "profiles", f"r02_{workload}_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(ROOT, "profiles", f"r03_{workload}_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
 

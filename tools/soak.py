@@ -19,12 +19,14 @@ W = X[torch.randperm(n, device=dev, generator=g)[:M]].double().cpu().numpy()
 gamma = float(1.0 / X.double().var(dim=0, unbiased=False).sum().item())
 hop = bench.lattice_hops(rows, cols)
 hip = HipBackend(0, algorithm="auto"); hip.load_device(X)
+if "refine" in sys.argv[4:]:   # the per-sample refinement in every filtered search (default: by measurement)
+    hip.refine = 1
 torch.cuda.synchronize(); m0 = torch.cuda.memory_allocated()
 t0 = time.time(); hip.set_weights(W); b0 = hip._get("device_bytes")
 arms = {}
 for e in range(n_epochs):
     hip.epoch(RESIDENT, hop, max(0.7, 4.0 * 0.999 ** e), gamma, "aligned", False, keep_on_device=True)
-    key = hip.filter_log[-1][0] if hip.filter_log[-1][0] != "filtered" else f"filtered/{hip.filter_log[-1][2]}"
+    key = hip.filter_log[-1][0] if hip.filter_log[-1][0] != "filtered" else f"filtered/{hip.filter_log[-1][2]}" + ("+refined" if hip.refined else "")
     arms[key] = arms.get(key, 0) + 1
 Wd = hip.get_weights(0)
 print("searches run:", arms)
