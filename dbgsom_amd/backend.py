@@ -292,6 +292,9 @@ class HipBackend(HotPathBackend):
     # the first epochs of a map size with and without it and keeps the faster form
     refine = property(lambda self: self._get("refine"), lambda self, v: self._set("refine", int(v)))
     refined = property(lambda self: bool(self._get("refined")))   # what the last filtered search ran
+    # with the refinement: the distance of a sample it decided is evaluated inside the sums kernel of the
+    # epoch (one pass over the float rows for distance and sums) -- 1 (default) / 0
+    defer = property(lambda self: bool(self._get("defer")), lambda self, v: self._set("defer", int(bool(v))))
     planes_cached = property(lambda self: bool(self._get("planes_cached")))
     padded_features = property(lambda self: self._get("padded_features"))
 
@@ -708,7 +711,7 @@ class HipBackend(HotPathBackend):
         self._call("dbgsom_ctx_subset_create", self._ctx, int(neuron), ctypes.byref(child))
         return HipBackend(self.device_index, self.algorithm, _ctx=child)
 
-    _SETTABLE = ("algorithm", "sweep_planes", "seed_stride", "timing", "graph", "refine",
+    _SETTABLE = ("algorithm", "sweep_planes", "seed_stride", "timing", "graph", "refine", "defer",
                  "filter_min_query_rows", "max_mean_candidates")
 
     def release(self):

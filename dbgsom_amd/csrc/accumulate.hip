@@ -349,6 +349,261 @@ __global__ __launch_bounds__(AT) void segsum_kernel(
     }
 }
 
+// ---- 5b. the same chunk, with the distances of the rows that do not have one yet ----------------------
+// The refinement of the filtered search (filter.hip 2d) knows the winner of a sample whose candidates it
+// could narrow down to ONE without ever touching the sample's float rows; its distance is the float64 chain
+// against that one prototype -- against THIS chunk's prototype.  Such rows arrive with dist == -1: the
+// chunk's rows are brought into LDS in sub-blocks of SR whole rows (LDS-DMA, two buffers), one lane per row
+// runs the chain acc = fma(w_k, x_k, acc), k ascending (the arithmetic of every exact BMU kernel: same
+// bits), then all threads form the weighted sums from the same LDS image -- the float rows are streamed
+// ONCE for the distance and the sums (pair kernel + segsum: twice).  Sums, their order of additions and
+// the scalar partials are those of segsum_kernel bit for bit.
+typedef __attribute__((address_space(3))) void *acc_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *acc_gbl_ptr_t;
+__device__ __forceinline__ void acc_dma16(const void *src, void *lds_dst) {
+    __builtin_amdgcn_global_load_lds((acc_gbl_ptr_t)src, (acc_lds_ptr_t)lds_dst, 16, 0, 0);
+}
+constexpr int SR = 16;   // rows per sub-block (lanes of the chain)
+constexpr int SD_QG = 4; // column groups a thread keeps across the sub-blocks of a chunk (rows of <= 4 AT groups)
+
+struct SegDistLds {   // byte offsets inside the one dynamic LDS object
+    int buf_bytes, o_w, o_rows, o_kw, o_dist, o_red, o_info, total;
+};
+static SegDistLds segdist_lds(int64_t d, size_t es, int vec) {
+    SegDistLds l;
+    l.buf_bytes = (int)(((size_t)SR * d * es + 1023) / 1024 * 1024);
+    l.o_w = 2 * l.buf_bytes;
+    l.o_rows = l.o_w + (int)d * 8;
+    l.o_kw = l.o_rows + CH * 4;
+    l.o_dist = l.o_kw + CH * 8;
+    l.o_red = l.o_dist + CH * 8;
+    l.o_info = l.o_red + AT * vec * 8;
+    l.total = l.o_info + 16;
+    return l;
+}
+
+template <typename XT, int VEC>
+__device__ __forceinline__ void lds_vec(const char *src, double (&v)[VEC]) {
+    if constexpr (sizeof(XT) == 4 && VEC == 4) {
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const f4_t t4 = *reinterpret_cast<const f4_t *>(src);
+        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+    } else if constexpr (sizeof(XT) == 8 && VEC == 2) {
+        typedef double d2v_t __attribute__((ext_vector_type(2)));
+        const d2v_t t2 = *reinterpret_cast<const d2v_t *>(src);
+        v[0] = t2.x; v[1] = t2.y;
+    } else {
+        static_assert(sizeof(XT) == 2 && VEC == 8, "unsupported vector width");
+        typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+        const u4_t a = *reinterpret_cast<const u4_t *>(src);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = (double)__uint_as_float(a[e] << 16);
+            v[2 * e + 1] = (double)__uint_as_float(a[e] & 0xffff0000u);
+        }
+    }
+}
+
+template <typename XT, int VEC>
+__global__ __launch_bounds__(AT) void segsum_dist_kernel(
+    const XT *__restrict__ X, int d, int64_t ldx, const int32_t *__restrict__ order, double gamma,
+    double *__restrict__ dist, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ count,
+    const uint32_t *__restrict__ chunk_pre, int M, double *__restrict__ slab, const double *__restrict__ W,
+    const double *__restrict__ ww, const double *__restrict__ xx, int round_f32, SegDistLds L) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];   // ONE LDS object (see refine.h)
+    double *w_s = reinterpret_cast<double *>(dyn + L.o_w);
+    int32_t *rows_s = reinterpret_cast<int32_t *>(dyn + L.o_rows);
+    double *kw_s = reinterpret_cast<double *>(dyn + L.o_kw), *dist_s = reinterpret_cast<double *>(dyn + L.o_dist);
+    double *red = reinterpret_cast<double *>(dyn + L.o_red);
+    uint32_t *info = reinterpret_cast<uint32_t *>(dyn + L.o_info);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t c = blockIdx.x;
+    if (c >= chunk_pre[M]) return;  // uniform per workgroup
+    if (tid == 0) {
+        int lo = 0, hi = M;  // last j with chunk_pre[j] <= c
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (chunk_pre[mid] <= c) lo = mid; else hi = mid;
+        }
+        const uint32_t begin = seg_start[lo] + (c - chunk_pre[lo]) * CH;
+        const uint32_t end = min(begin + (uint32_t)CH, seg_start[lo] + count[lo]);
+        info[0] = begin; info[1] = end - begin; info[2] = (uint32_t)lo;
+    }
+    __syncthreads();
+    const uint32_t begin = info[0];
+    const int n = (int)info[1], j = (int)info[2];
+    if (tid < n) {
+        const int32_t r = order[begin + tid];
+        rows_s[tid] = r;
+        dist_s[tid] = dist[r];   // (-1: to be computed here)
+    }
+    for (int k = tid; k < d; k += AT) w_s[k] = W[(size_t)j * d + k];
+    const double ww_j = ww[j];
+    __syncthreads();
+    constexpr int ES = (int)sizeof(XT);
+    const int rowbytes = d * ES;
+    const int ninstr = L.buf_bytes / 1024;
+    // sub-block s into buffer s & 1: instruction i covers LDS bytes [1024 i, +1024) = 16-byte pieces of whole rows
+    auto issue = [&](int sb) {
+        char *buf = dyn + (sb & 1) * L.buf_bytes;
+        const int nrow = min(SR, n - sb * SR);
+        for (int i = wave; i < ninstr; i += AT / 64) {
+            const int a = i * 1024 + lane * 16;
+            int row = a / rowbytes;
+            const int off = a - row * rowbytes;
+            row = row < nrow ? row : nrow - 1;   // (behind the sub-block's rows: any valid address, never read)
+            acc_dma16(reinterpret_cast<const char *>(X + (int64_t)rows_s[sb * SR + row] * ldx) + off, buf + i * 1024);
+        }
+    };
+    const int nsub = (n + SR - 1) / SR;
+    const int Q = d / VEC;  // column groups (VEC divides d by construction)
+    const bool wide = Q >= AT;
+    const int RL = wide ? 1 : AT / Q;  // row lanes working side by side on the same column group (segsum_kernel)
+    const int rl = wide ? 0 : tid / Q, q0 = wide ? tid : tid - rl * Q;
+    // (narrow rows: acc[0] = this thread's column group for its row lane; wide rows: up to SD_QG column groups
+    //  q = tid + g AT per thread, kept in registers across the sub-blocks -- the launcher checks Q <= SD_QG AT)
+    double acc[SD_QG][VEC];
+#pragma unroll
+    for (int g = 0; g < SD_QG; ++g)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[g][e] = 0.0;
+    double *out = slab + (size_t)c * (d + 2);
+    issue(0);
+    for (int sb = 0; sb < nsub; ++sb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // sub-block sb has landed; buffer (sb + 1) & 1 has been summed
+        if (sb + 1 < nsub) issue(sb + 1);
+        const char *buf = dyn + (sb & 1) * L.buf_bytes;
+        const int nrow = min(SR, n - sb * SR);
+        if (tid < SR) {   // ---- the chains: lane = row
+            const int p = sb * SR + tid;
+            const bool need = tid < nrow && dist_s[p] == -1.0;
+            if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                const char *xr = buf + (tid < nrow ? tid : 0) * rowbytes;
+                double a = 0.0;
+                // 16 features per block, the NEXT block's LDS reads in flight under this block's 16 dependent
+                // fmas (sched_barriers: left alone the compiler reuses one register quad for every read and
+                // waits for each -- 24 exposed LDS round trips per block, 7 x the time of the chain itself)
+                // (raw 16-byte pieces are kept as they come and widened in the fma phase: the wait for a block's
+                //  reads then sits in front of ITS fmas, one block later)
+                typedef unsigned raw4_t __attribute__((ext_vector_type(4)));
+                constexpr int XR = ES;            // 16-byte pieces of 16 features of the row: 4 (f32), 8 (f64), 2 (bf16)
+                struct Blk { raw4_t x[XR]; raw4_t w[8]; };
+                auto load_block = [&](int k, Blk &b) {
+#pragma unroll
+                    for (int u = 0; u < XR; ++u) b.x[u] = *reinterpret_cast<const raw4_t *>(xr + k * ES + 16 * u);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) b.w[u] = *reinterpret_cast<const raw4_t *>(reinterpret_cast<const char *>(w_s + k) + 16 * u);
+                };
+                auto chain_block = [&](const Blk &b) {
+                    // (the prototype is the first factor, as the A operand of the matrix instruction)
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const raw4_t wq = b.w[u >> 1];
+                        const double wv = __hiloint2double((int)wq[2 * (u & 1) + 1], (int)wq[2 * (u & 1)]);
+                        double xv;
+                        if constexpr (ES == 4) {
+                            xv = (double)__uint_as_float(b.x[u >> 2][u & 3]);
+                        } else if constexpr (ES == 8) {
+                            const raw4_t xq = b.x[u >> 1];
+                            xv = __hiloint2double((int)xq[2 * (u & 1) + 1], (int)xq[2 * (u & 1)]);
+                        } else {
+                            const unsigned wd = b.x[u >> 3][(u & 7) >> 1];
+                            xv = (double)__uint_as_float((u & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                        }
+                        a = fma(wv, xv, a);
+                    }
+                };
+                Blk ba, bb;
+                load_block(0, ba);
+                for (int k = 0; k < d; k += 32) {   // (d % 16 == 0: the engine's padded rows)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k + 16 < d) load_block(k + 16, bb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    chain_block(ba);
+                    if (k + 16 >= d) break;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k + 32 < d) load_block(k + 32, ba);
+                    __builtin_amdgcn_sched_barrier(0);
+                    chain_block(bb);
+                }
+                if (need) {
+                    const int32_t r = rows_s[p];
+                    double rv = (xx[r] + (-2.0 * a)) + ww_j;
+                    if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
+                    double dv = sqrt(rv);
+                    if (round_f32) dv = (double)(float)dv;
+                    dist_s[p] = dv;
+                    dist[r] = dv;
+                }
+            }
+            if (tid < nrow) {
+                const double dd = dist_s[p];
+                // the sample kernel of BaseSom._calculate_exp_similarity (BaseSom.py:533-538), the arithmetic
+                // of exp_similarity_kernel (bmu.hip) and of segsum_kernel
+                kw_s[p] = 1.0 - sqrt(1.0 - exp(-gamma * (dd * dd)));
+            }
+        }
+        __syncthreads();
+        // ---- the weighted sums of this sub-block's rows, in list order (segsum_kernel's order)
+        if (wide) {
+#pragma unroll
+            for (int g = 0; g < SD_QG; ++g) {
+                const int q = tid + g * AT;
+                if (q < Q)
+                    for (int t = 0; t < nrow; ++t) {
+                        const double w = kw_s[sb * SR + t];
+                        double v[VEC];
+                        lds_vec<XT, VEC>(buf + t * rowbytes + q * VEC * ES, v);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[g][e] += w * v[e];
+                    }
+            }
+        } else if (rl < RL) {
+            // (row lane rl takes the chunk's rows p = rl, rl + RL, ...)
+            int t = (rl - (sb * SR) % RL + RL) % RL;
+            for (; t < nrow; t += RL) {
+                const double w = kw_s[sb * SR + t];
+                double v[VEC];
+                lds_vec<XT, VEC>(buf + t * rowbytes + q0 * VEC * ES, v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[0][e] += w * v[e];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == AT - 1) {  // the scalar partials, in list order
+        double sk = 0.0, se = 0.0;
+        for (int p = 0; p < n; ++p) { sk += kw_s[p]; se += dist_s[p]; }
+        out[d] = sk;
+        out[d + 1] = se;
+    }
+    if (wide) {
+#pragma unroll
+        for (int g = 0; g < SD_QG; ++g) {
+            const int q = tid + g * AT;
+            if (q < Q)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) out[q * VEC + e] = acc[g][e];
+        }
+    } else {
+        if (rl < RL) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) red[(rl * Q + q0) * VEC + e] = acc[0][e];
+        }
+        __syncthreads();
+        if (rl == 0) {  // row lanes are added in lane order
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                double s = red[q0 * VEC + e];
+                for (int u = 1; u < RL; ++u) s += red[(u * Q + q0) * VEC + e];
+                out[q0 * VEC + e] = s;
+            }
+        }
+    }
+}
+
 // ---- 6. add each neuron's chunk partials in chunk order --------------------------------------
 __global__ __launch_bounds__(AT) void finalize_kernel(const double *__restrict__ slab, int d,
                                                       int M, const uint32_t *__restrict__ count,
@@ -457,10 +712,17 @@ int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order,
 }
 
 // ---------------------------------------------------------------------------------------------
+bool accumulate_can_fill_distances(int x_dtype, int64_t d) {
+    if (d % 16 != 0) return false;
+    const int vec = x_dtype == DBGSOM_F32 ? 4 : (x_dtype == DBGSOM_F64 ? 2 : 8);
+    if (d / vec > (int64_t)SD_QG * AT) return false;
+    return segdist_lds(d, dtype_size(x_dtype), vec).total <= 160 * 1024;
+}
+
 static int accumulate_impl(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                            const int64_t *idx, const double *kw, double gamma, const double *dist, int64_t M,
                            double *sums, int32_t *status, bool status_behind_sums, void *ws,
-                           size_t ws_bytes, hipStream_t s) {
+                           size_t ws_bytes, hipStream_t s, const DistFill *fill = nullptr) {
     DBGSOM_REQUIRE(valid_dtype(x_dtype), "x_dtype must be DBGSOM_F32/F64/BF16");
     DBGSOM_REQUIRE(N >= 0 && N < 0x7fffffff && d >= 1 && d <= 0x7ffffff0 && ldx >= d, "bad sample shape");
     DBGSOM_REQUIRE(M >= 1 && M <= DBGSOM_MAX_PROTOTYPES, "M outside [1, DBGSOM_MAX_PROTOTYPES]");
@@ -495,7 +757,29 @@ static int accumulate_impl(const void *X, int x_dtype, int64_t N, int64_t d, int
 #define DBGSOM_SEGSUM(XT, V)                                                                    \
     hipLaunchKernelGGL((segsum_kernel<XT, V>), grid, block, 0, s, (const XT *)X, di, ldx, w.order, \
                        kw, gamma, dist, w.seg_start, w.count, w.chunk_pre, Mi, w.slab)
-    if (x_dtype == DBGSOM_F32) {
+    if (fill) {
+        // rows with dist == -1 get their distance (to their winner: this chunk's prototype) on the way
+        DBGSOM_REQUIRE(!kw && al16 && accumulate_can_fill_distances(x_dtype, d) && fill->W && fill->ww && fill->xx,
+                       "distances cannot be filled in for this shape");
+        const int vec = x_dtype == DBGSOM_F32 ? 4 : (x_dtype == DBGSOM_F64 ? 2 : 8);
+        const SegDistLds L = segdist_lds(d, xe, vec);
+#define DBGSOM_SEGDIST(XT, V)                                                                             \
+    do {                                                                                                  \
+        static int attr_set = 0;                                                                          \
+        if (attr_set < L.total) {                                                                         \
+            DBGSOM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&segsum_dist_kernel<XT, V>), \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = 160 * 1024;                                                                        \
+        }                                                                                                 \
+        hipLaunchKernelGGL((segsum_dist_kernel<XT, V>), grid, block, (size_t)L.total, s, (const XT *)X, di, ldx, \
+                           w.order, gamma, const_cast<double *>(dist), w.seg_start, w.count, w.chunk_pre, Mi, \
+                           w.slab, fill->W, fill->ww, fill->xx, fill->round_f32, L);                      \
+    } while (0)
+        if (x_dtype == DBGSOM_F32) DBGSOM_SEGDIST(float, 4);
+        else if (x_dtype == DBGSOM_F64) DBGSOM_SEGDIST(double, 2);
+        else DBGSOM_SEGDIST(bf16_t, 8);
+#undef DBGSOM_SEGDIST
+    } else if (x_dtype == DBGSOM_F32) {
         if (al16 && d % 4 == 0) DBGSOM_SEGSUM(float, 4); else DBGSOM_SEGSUM(float, 1);
     } else if (x_dtype == DBGSOM_F64) {
         if (al16 && d % 2 == 0) DBGSOM_SEGSUM(double, 2); else DBGSOM_SEGSUM(double, 1);
@@ -523,8 +807,9 @@ int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t 
 
 int launch_accumulate_epoch(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                             const int64_t *idx, double gamma, const double *dist, int64_t M,
-                            double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s) {
-    return accumulate_impl(X, x_dtype, N, d, ldx, idx, nullptr, gamma, dist, M, sums, status, true, ws, ws_bytes, s);
+                            double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s,
+                            const DistFill *fill) {
+    return accumulate_impl(X, x_dtype, N, d, ldx, idx, nullptr, gamma, dist, M, sums, status, true, ws, ws_bytes, s, fill);
 }
 
 }  // namespace dbgsom

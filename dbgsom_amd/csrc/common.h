@@ -99,9 +99,18 @@ int launch_accumulate(const void *X, int x_dtype, int64_t N, int64_t d, int64_t 
 // the same with the sample kernel computed on the fly (kw_i = 1 - sqrt(1 - exp(-gamma dist_i^2)),
 // the arithmetic of dbgsom_exp_similarity) and the status flag also left as a float64 behind the
 // sums (sums[M (d + 3)]: it rides in the all-reduce buffer): two launches less per epoch
+// `fill`: rows whose distance is still -1 (the filtered search knew their winner without evaluating it:
+// FilteredCall::defer_dist) get it inside the sums kernel -- the chain against their winner, W / ww = the
+// epoch's prototypes and their norms, xx = the samples' norms; `dist` is then written too
+struct DistFill {
+    const double *W = nullptr, *ww = nullptr, *xx = nullptr;
+    int round_f32 = 0;
+};
+bool accumulate_can_fill_distances(int x_dtype, int64_t d);
 int launch_accumulate_epoch(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
                             const int64_t *idx, double gamma, const double *dist, int64_t M,
-                            double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s);
+                            double *sums, int32_t *status, void *ws, size_t ws_bytes, hipStream_t s,
+                            const DistFill *fill = nullptr);
 size_t bucket_sort_workspace_bytes(int64_t N, int64_t M);
 int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order, void *ws,
                        hipStream_t s);
@@ -130,6 +139,9 @@ struct FilteredCall {
     const double *hint_dist = nullptr, *hint_shift = nullptr;
     // per-sample refinement of the candidate lists (2d): 0 = off, else the longest list it should take
     int refine_rows = 0;
+    // (with the refinement) a sample whose candidates narrow down to ONE gets its winner and dist = -1: the
+    // caller evaluates that distance itself, on its own pass over the rows (launch_accumulate_epoch's `fill`)
+    bool defer_dist = false;
     // the stored rows when they are not what X points to (bfloat16 storage behind a float32 copy): the
     // pair kernel of the refinement streams these
     const void *X_store = nullptr;

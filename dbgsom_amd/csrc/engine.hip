@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <new>
 #include <vector>
 
@@ -241,7 +242,12 @@ struct dbgsom_ctx {
     // (the exact stage of the first training epochs of a map size is timed with and without it -- HIP
     // events on the stream -- and the faster form kept; re-measured when the lists change by a quarter)
     int refine = 2;
-    double rf_ms[2] = {NAN, NAN};   // exact stage without / with the refinement
+    double rf_ms[2] = {NAN, NAN};   // epoch (wall clock of the blocking call) without / with the refinement: best of two
+    int rf_n[2] = {0, 0};
+    int defer = 0;                  // with the refinement: distances of decided samples inside the sums kernel
+                                    // (experimental, off: one chain wavefront per CU cannot keep up -- NOTES.md)
+    bool last_deferred = false;
+    int last_round_f32 = 0;
     int64_t rf_M = -1;
     double rf_mean_ref = NAN;
     int rf_measuring = -1;          // the form the running call is timing (-1: none)
@@ -457,7 +463,8 @@ int stage_weights(dbgsom_ctx *c, const double *W_host, int64_t M, int64_t d, int
 
 // k = 1 search through the int8 filter; seeds = previous winners when `hinted`
 int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t M, int round_f32,
-                 const int64_t *prev_idx, const int32_t *order, int64_t *idx, double *dist, bool may_probe = false) {
+                 const int64_t *prev_idx, const int32_t *order, int64_t *idx, double *dist, bool may_probe = false,
+                 bool allow_defer = false) {
     TRY(ensure_planes(c, s));
     TRY(ws.reserve_zeroed(dbgsom_bmu_filtered_workspace_bytes(s.N, s.dp, M), c->stream));
     c->planes_used = planes_for_call(c);
@@ -494,24 +501,28 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     const bool mean_known = c->last_mean == c->last_mean && c->last_filter_M == M;
     if (mean_known) rf_rows = (int)(c->last_mean * 1.25 + 8.0);
     bool use_refine = c->refine == 1;
-    if (c->rf_measuring >= 0 && !c->timing) (void)dbgsom_filter_timing(0);  // (a measurement nobody read)
     c->rf_measuring = -1;
     if (c->refine == 2 && mean_known) {
         if (c->rf_M != M || !(fabs(c->last_mean - c->rf_mean_ref) <= 0.25 * c->rf_mean_ref)) {
-            c->rf_M = M; c->rf_mean_ref = c->last_mean; c->rf_ms[0] = c->rf_ms[1] = NAN;
+            c->rf_M = M; c->rf_mean_ref = c->last_mean; c->rf_ms[0] = c->rf_ms[1] = NAN; c->rf_n[0] = c->rf_n[1] = 0;
         }
         // prior (what has not been measured is not tried blind): the refinement reads two digit planes and the
         // rows once more whatever the lists are -- short lists, few features or a few workgroups never pay;
         // lists beyond twice its largest tile stay the matrix-core stage's anyway
         const bool eligible = c->last_mean >= 24.0 && c->last_mean <= 400.0 && s.dp >= 256 && s.N >= 65536;
         if (!eligible) use_refine = false;
-        else if (may_probe && c->rf_ms[0] != c->rf_ms[0]) { use_refine = false; c->rf_measuring = 0; }
-        else if (may_probe && c->rf_ms[1] != c->rf_ms[1]) { use_refine = true; c->rf_measuring = 1; }
-        else use_refine = c->rf_ms[1] < c->rf_ms[0];   // (false while either is unknown)
+        else if (may_probe && c->rf_n[0] < 2) { use_refine = false; c->rf_measuring = 0; }
+        else if (may_probe && c->rf_n[1] < 2) { use_refine = true; c->rf_measuring = 1; }
+        else use_refine = c->rf_n[0] >= 2 && c->rf_n[1] >= 2 && c->rf_ms[1] < c->rf_ms[0];
     }
-    if (c->rf_measuring >= 0 && !c->timing) TRY(dbgsom_filter_timing(1));
     call.refine_rows = use_refine ? rf_rows : 0;
     c->last_refined = use_refine;
+    // an epoch's accumulate step can evaluate the distances of the samples the refinement decided without
+    // looking at their float rows: one pass over those rows for the distance AND the sums
+    call.defer_dist = use_refine && allow_defer && c->defer && M < 0xffff &&
+                      accumulate_can_fill_distances(s.dtype, s.dp);
+    c->last_deferred = call.defer_dist;
+    c->last_round_f32 = round_f32;
     if (s.dtype == DBGSOM_BF16) { call.X_store = s.X; call.store_dtype = DBGSOM_BF16; call.ld_store = s.dp; }
     TRY(launch_bmu_filtered(call));
     c->last_filter_M = M; c->last_filter_N = s.N; c->last_filter_d = s.dp; c->last_filter_ws = ws.p;
@@ -753,13 +764,14 @@ int epoch_bmu(dbgsom_ctx *c, int64_t M, int round_f32) {
     int64_t *out = c->idx[c->icur ^ 1].as<int64_t>();
     const double *W = c->Wb[c->cur].as<double>();
     c->last_hinted = false;
+    c->last_deferred = false;
     if (filter_applies(c, M)) {
         const bool hint = (c->algorithm == DBGSOM_ALG_AUTO || c->algorithm == DBGSOM_ALG_FILTERED_HINT) &&
                           c->hint_valid && c->hintM <= M;
         c->last_filtered = true;
         c->last_hinted = hint;
         TRY(run_filtered(c, s, c->filt_ws, W, M, round_f32, hint ? c->idx[c->icur].as<int64_t>() : nullptr,
-                         hint ? c->acc_ws.as<int32_t>() : nullptr, out, c->dist.as<double>(), true));
+                         hint ? c->acc_ws.as<int32_t>() : nullptr, out, c->dist.as<double>(), true, true));
     } else {
         c->last_filtered = false;
         if (c->filter_backoff > 0) --c->filter_backoff;
@@ -791,8 +803,12 @@ int accumulate_and_reduce(dbgsom_ctx *c, const int64_t *idx, const double *kw, d
         hipLaunchKernelGGL(status_to_f64_kernel, dim3(1), dim3(1), 0, c->stream, status, c->sums.as<double>() + count);
         TRY(launch_status("status_to_f64_kernel"));
     } else {
+        DistFill fill;
+        fill.W = c->Wb[c->cur].as<double>(); fill.ww = c->ww.as<double>(); fill.xx = s.xx.as<double>();
+        fill.round_f32 = c->last_round_f32;
         TRY(launch_accumulate_epoch(s.X, s.dtype, s.N, s.dp, s.dp, idx, gamma, dist, M, c->sums.as<double>(), status,
-                                    c->acc_ws.p, c->acc_ws.cap, c->stream));
+                                    c->acc_ws.p, c->acc_ws.cap, c->stream, c->last_deferred ? &fill : nullptr));
+        c->last_deferred = false;
     }
     c->sumsM = M;
     return run_allreduce(c, c->sums.as<double>(), count + 1);
@@ -835,13 +851,8 @@ int smooth_and_fetch(dbgsom_ctx *c, int64_t M, double sigma, int layout, int fla
     if (dist_host) DBGSOM_HIP_CHECK(hipMemcpyAsync(dist_host, c->dist.p, (size_t)s.N * 8, hipMemcpyDeviceToHost, c->stream));
     TRY(sync(c));
     c->ev_valid = c->timing != 0;
-    if ((c->timing || c->rf_measuring >= 0) && c->last_filtered) {
+    if (c->timing && c->last_filtered) {
         c->filter_ms_valid = dbgsom_bmu_filtered_stage_ms(c->filter_ms) == DBGSOM_OK;
-        if (c->rf_measuring >= 0) {
-            if (c->filter_ms_valid) c->rf_ms[c->rf_measuring] = c->filter_ms[4];
-            if (!c->timing) { (void)dbgsom_filter_timing(0); c->filter_ms_valid = false; }
-            c->rf_measuring = -1;
-        }
     } else {
         c->filter_ms_valid = false;
     }
@@ -976,10 +987,12 @@ int dbgsom_ctx_set_option(dbgsom_ctx *c, const char *name, int64_t v) {
         TRY(dbgsom_filter_timing(c->timing));
     } else if (!strcmp(name, "graph")) {
         c->use_graph = v != 0;
+    } else if (!strcmp(name, "defer")) {
+        c->defer = v != 0;
     } else if (!strcmp(name, "refine")) {
         DBGSOM_REQUIRE(v >= 0 && v <= 2, "refine must be 0 (off), 1 (on) or 2 (by measurement)");
         c->refine = (int)v;
-        c->rf_ms[0] = c->rf_ms[1] = NAN;
+        c->rf_ms[0] = c->rf_ms[1] = NAN; c->rf_n[0] = c->rf_n[1] = 0;
     } else if (!strcmp(name, "filter_min_query_rows")) {
         DBGSOM_REQUIRE(v >= 0, "filter_min_query_rows must be >= 0");
         c->filter_min_query_rows = v;
@@ -1003,6 +1016,7 @@ int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
     else if (!strcmp(name, "graph")) *v = c->use_graph;
     else if (!strcmp(name, "refine")) *v = c->refine;
     else if (!strcmp(name, "refined")) *v = c->last_refined ? 1 : 0;
+    else if (!strcmp(name, "defer")) *v = c->defer;
     else if (!strcmp(name, "k2_filtered")) *v = c->last_k2_filtered ? 1 : 0;
     else if (!strcmp(name, "filter_min_query_rows")) *v = c->filter_min_query_rows;
     else if (!strcmp(name, "max_mean_candidates")) *v = c->max_mean_candidates;
@@ -1064,7 +1078,7 @@ static void reset_training_state(dbgsom_ctx *c) {
     c->sumsM = 0;
     // the resident prototypes were laid out for the old samples' padded row length: gone with them
     c->M = c->otherM = 0;
-    c->rf_M = -1; c->rf_ms[0] = c->rf_ms[1] = NAN;
+    c->rf_M = -1; c->rf_ms[0] = c->rf_ms[1] = NAN; c->rf_n[0] = c->rf_n[1] = 0;
 }
 
 int dbgsom_ctx_load(dbgsom_ctx *c, const void *X_host, int x_dtype, int64_t N, int64_t d, int storage) {
@@ -1364,8 +1378,11 @@ int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f
     do {
         if ((rc = stage_weights(c, W_host, M, s.d, s.dp))) break;
         mark(c, 0);
+        const auto t_begin = std::chrono::steady_clock::now();
         if ((rc = epoch_bmu(c, M, round_f32))) break;
         mark(c, 1);
+        const int measuring = c->rf_measuring;   // (the refinement's policy: this epoch times one of the two forms)
+        c->rf_measuring = -1;
         const int64_t *idx = c->idx[c->icur].as<int64_t>();
         if ((rc = accumulate_and_reduce(c, idx, nullptr, gamma, c->dist.as<double>(), M))) break;
         // the next epoch's filter visits the samples bucketed by this epoch's winners: the stable
@@ -1376,6 +1393,11 @@ int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f
         rc = smooth_and_fetch(c, M, sigma, layout, flags, W_new_host, change_total_host, errors_host, activations_host,
                               idx, idx_host, dist_host);
         if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) break;
+        if (measuring >= 0) {   // wall clock of the blocking call behind the upload of W: BMU + sums + smoothing
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+            c->rf_ms[measuring] = c->rf_n[measuring] == 0 ? ms : fmin(ms, c->rf_ms[measuring]);
+            ++c->rf_n[measuring];
+        }
         c->last_frozen = (flags & DBGSOM_EPOCH_FROZEN) != 0;
         update_policy(c, c->tail.as<double>()[2 * M + 2], c->tail.as<double>()[2 * M + 3], c->tail.as<double>()[2 * M + 4],
                       (s.N + 127) / 128, M);

@@ -2413,7 +2413,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t o15 = take((size_t)TS_RB * 2 * dpad * 8);
     const size_t o3 = take((size_t)nb * Mpad * 2), o4 = take((size_t)nb * 4);
     const size_t o5 = take((size_t)N * 8), o6 = take((size_t)N * 4);
-    const size_t o7 = take(bucket_sort_workspace_bytes(N, M));
+    const size_t o7 = take(bucket_sort_workspace_bytes(N, M + 1));   // (+ 1: the "decided" bucket of the deferred form, 2d)
     const size_t o16 = take((size_t)nb * 4), o17 = take((size_t)(SCHED_CTR + 2 * RF_CTR + 4) * 4);
     const size_t o24 = take((size_t)2 * nb * 4);
     const size_t o25 = take((size_t)N * 8), o26 = take((size_t)N * 4), o27 = take((size_t)N * 8);
@@ -2622,6 +2622,7 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
     // k = 2 (the two nearest prototypes: topographic error, BaseSom.py:945): the pruning form only
     const bool k2 = call.k == 2;
     DBGSOM_REQUIRE(call.k == 1 || call.k == 2, "k must be 1 or 2");
+    DBGSOM_REQUIRE(!call.defer_dist || (call.refine_rows > 0 && M < 0xffff), "deferred distances need the refinement");
     DBGSOM_REQUIRE(!k2 || (prune && call.refine_rows == 0 && M >= 2),
                    "k = 2 needs the pruning form (DBGSOM_PRUNE, M <= 8192) without the refinement");
     seed_stride &= ~(DBGSOM_PRUNE | DBGSOM_PRUNE_PROBE | DBGSOM_PRUNE_RETRY);
@@ -2794,12 +2795,13 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
     // refinement and the pair kernel on the caller's; the samples whose candidates overflowed on the third.
     hipStream_t s_mfma = refine ? s2 : s;
     const int rows0 = rf_rows <= 32 ? 32 : (rf_rows <= 64 ? 64 : (rf_rows <= 128 ? 128 : 0));
+    const int defer_M = (refine && call.defer_dist) ? (int)M : 0;
     if (refine)
         // list-length classes of the refinement: a small tile for the bulk (what the caller expects the
         // lists to be), the largest for the rest; workgroups in neither stay the matrix-core stage's
         hipLaunchKernelGGL(class_fill_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount, (int)f.nb,
                            rows0, RF_SEGS * (int)RefineCfg<2, 4>::MAX_CNT, f.rf_queue, f.rf_qlen, f.gflag, f.sched_ctr, order_dev,
-                           prev_idx_dev, N, (int)M, f.cand, f.rbest);
+                           prev_idx_dev, N, (int)M, f.cand, f.rbest, defer_M);
     else
         // (the bin counts were added up by the sweep's workgroups as they wrote their list lengths)
         hipLaunchKernelGGL(sched_fill_kernel, dim3((unsigned)((f.nb + 255) / 256)), dim3(256), 0, s, f.ucount,
@@ -2821,7 +2823,7 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
     hipLaunchKernelGGL((refine_i8_kernel<NJ_, JT_>), dim3((unsigned)((f.nb + 7) / 8 * 8 < (WGS) ? (f.nb + 7) / 8 * 8 : (WGS))), dim3(NJ_ * 256), 0, s, \
                        xb.planes, xb.scale, xb.res16, xx_dev, N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, ww_dev,    \
                        f.summary, order_dev, f.ulist, (int)f.Mpad, f.ucount, f.rf_queue + (size_t)(CLS) * f.nb,      \
-                       f.rf_qlen + (CLS), f.cand, f.rbest, f.rf_ctr, f.ovf, f.rf_qlen + 2)
+                       f.rf_qlen + (CLS), f.cand, f.rbest, f.rf_ctr, f.ovf, f.rf_qlen + 2, defer_M, idx_dev, dist_dev)
         static const int wgs_env = [] {   // DBGSOM_REFINE_WGS: workgroups per launch (diagnostics; a multiple of 8)
             const char *e = getenv("DBGSOM_REFINE_WGS");
             return e ? atoi(e) / 8 * 8 : 0;
@@ -2833,20 +2835,22 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         DBGSOM_REFINE_LAUNCH(2, 4, 1, wgs2);
 #undef DBGSOM_REFINE_LAUNCH
         // the samples by their refined best prototype: a workgroup of the pair kernel then shares its candidates
-        const int rc = launch_bucket_sort(f.rbest, N, M, f.order2, f.sort_ws, s);
+        const int64_t Mk = defer_M ? M + 1 : M;   // (deferred: the decided samples behind every real bucket)
+        const int rc = launch_bucket_sort(f.rbest, N, Mk, f.order2, f.sort_ws, s);
         if (rc != DBGSOM_OK) return rc;
+        const uint32_t *n_active = defer_M ? bucket_sort_seg_start(f.sort_ws, N, Mk) + M : (const uint32_t *)nullptr;
         // (bfloat16-resident samples: the pair kernel reads the stored rows -- half the bytes of the widened
         //  copy the matrix kernels use, the same values)
         const unsigned pgrid = (unsigned)(((N + PS - 1) / PS + 7) / 8 * 8);   // (whole rounds of the 8 XCDs: xcd_group)
         if (call.X_store && call.store_dtype == DBGSOM_BF16 && x_dtype == DBGSOM_F32)
             hipLaunchKernelGGL((pair_exact_kernel<bf16_t, 32, 128>), dim3(pgrid), dim3(256), 0, s, (const bf16_t *)call.X_store, N,
-                               (int)d, call.ld_store, xx_dev, W_dev, ww_dev, f.order2, f.cand, round_f32, idx_dev, dist_dev, f.rf_ctr);
+                               (int)d, call.ld_store, xx_dev, W_dev, ww_dev, f.order2, f.cand, round_f32, idx_dev, dist_dev, f.rf_ctr, n_active);
         else if (x_dtype == DBGSOM_F32)
             hipLaunchKernelGGL((pair_exact_kernel<float, 16, 256>), dim3(pgrid), dim3(256), 0, s, (const float *)X_dev, N,
-                               (int)d, ldx, xx_dev, W_dev, ww_dev, f.order2, f.cand, round_f32, idx_dev, dist_dev, f.rf_ctr);
+                               (int)d, ldx, xx_dev, W_dev, ww_dev, f.order2, f.cand, round_f32, idx_dev, dist_dev, f.rf_ctr, n_active);
         else
             hipLaunchKernelGGL((pair_exact_kernel<double, 16, 256>), dim3(pgrid), dim3(256), 0, s, (const double *)X_dev, N,
-                               (int)d, ldx, xx_dev, W_dev, ww_dev, f.order2, f.cand, round_f32, idx_dev, dist_dev, f.rf_ctr);
+                               (int)d, ldx, xx_dev, W_dev, ww_dev, f.order2, f.cand, round_f32, idx_dev, dist_dev, f.rf_ctr, n_active);
         // (the samples whose candidates overflowed: behind the pair kernel, not beside it -- its uncoalesced
         //  row walks slowed the sort and the pair kernel by more than it takes)
         if (x_dtype == DBGSOM_F32)

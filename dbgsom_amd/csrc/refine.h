@@ -69,7 +69,11 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
     const uint32_t *__restrict__ ucount, const int32_t *__restrict__ queue, const uint32_t *__restrict__ queue_len,
     unsigned long long *__restrict__ cand, int64_t *__restrict__ rbest, unsigned long long *__restrict__ rf_ctr,
-    int32_t *__restrict__ ovf, uint32_t *__restrict__ ovf_len) {
+    int32_t *__restrict__ ovf, uint32_t *__restrict__ ovf_len, int defer_M, int64_t *__restrict__ idx_out,
+    double *__restrict__ dist_out) {
+    // defer_M > 0 (= M; FilteredCall::defer_dist): a sample left with ONE candidate has its winner -- written
+    // here with dist = -1, evaluated by the caller on its own pass over the rows -- and leaves the pair
+    // kernel's work (bucket key M: behind every real bucket); only the undecided samples are bucketed.
     // (one launch per list-length class, a few workgroups per CU walking the class's queue of 128-sample
     //  workgroups -- class_fill_kernel)
     using C = RefineCfg<NJ, JT>;
@@ -331,8 +335,18 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
             ovf[2 * (size_t)k + 1] = group;
             n = 0;
         }
+        int64_t key = (int64_t)g_best;  // bucket key of the pair kernel: any prototype does, the likely winner is best
+        if (defer_M > 0) {
+            if (n == 1) {
+                idx_out[isamp] = (int64_t)(slots & 0xffffull);
+                dist_out[isamp] = -1.0;
+                slots = RF_NONE;
+                n = 0;
+            }
+            if (n == 0) key = (int64_t)defer_M;   // (decided, or the overflow kernel's)
+        }
         cand[isamp] = slots;
-        rbest[isamp] = (int64_t)g_best;  // bucket key of the pair kernel: any prototype does, the likely winner is best
+        rbest[isamp] = key;
         atomicAdd(&misc[8], (uint32_t)n);
     }
     __syncthreads();
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(256) void class_fill_kernel(const uint32_t *__restr
                                                          const int32_t *__restrict__ order,
                                                          const int64_t *__restrict__ prev, int64_t N, int M,
                                                          unsigned long long *__restrict__ cand,
-                                                         int64_t *__restrict__ rbest) {
+                                                         int64_t *__restrict__ rbest, int defer_M) {
     __shared__ uint32_t h[3], base[2];
     __shared__ int skipped[256];
     if (threadIdx.x < 3) h[threadIdx.x] = 0u;
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(256) void class_fill_kernel(const uint32_t *__restr
         if (p < N) {
             const int64_t i = order[p], q = prev[i];
             cand[i] = RF_NONE;
-            rbest[i] = (q >= 0 && q < M) ? q : 0;
+            rbest[i] = defer_M > 0 ? (int64_t)defer_M : ((q >= 0 && q < M) ? q : 0);
         }
     }
     __syncthreads();
@@ -403,7 +417,8 @@ __global__ __launch_bounds__(256, 2) void pair_exact_kernel(
     const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
     const double *__restrict__ W, const double *__restrict__ ww, const int32_t *__restrict__ order2,
     const unsigned long long *__restrict__ cand, int round_f32, int64_t *__restrict__ idx_out,
-    double *__restrict__ dist_out, unsigned long long *__restrict__ rf_ctr) {
+    double *__restrict__ dist_out, unsigned long long *__restrict__ rf_ctr, const uint32_t *__restrict__ n_active) {
+    // n_active (FilteredCall::defer_dist): the first *n_active positions of order2 hold the undecided samples
     constexpr int STAGES = 3;
     constexpr int ES = (int)sizeof(XT);
     constexpr int KP = PIECE / ES;              // features per tile: 64 (float32, bfloat16 in 128-byte pieces) / 32 (float64)
@@ -430,8 +445,12 @@ __global__ __launch_bounds__(256, 2) void pair_exact_kernel(
     uint8_t *psamp = reinterpret_cast<uint8_t *>(smem + O_PSAMP);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t p0 = (int64_t)xcd_group((int)blockIdx.x, (int)gridDim.x) * PS;
-    if (p0 >= N) return;
+    const int64_t NA = n_active ? (int64_t)*n_active : N;   // (the positions that can hold pairs)
+    // (the eight XCDs share the ACTIVE workgroups: an eighth of them each, contiguous)
+    const int ng8 = (int)(((NA + PS - 1) / PS + 7) / 8 * 8);
+    if ((int)blockIdx.x >= ng8) return;
+    const int64_t p0 = (int64_t)xcd_group((int)blockIdx.x, ng8) * PS;
+    if (p0 >= NA) return;
 
     // ---- pairs and the distinct candidates --------------------------------------------------------
     for (int h = tid; h < RF_HASH; h += 256) table[h] = 0xffffffffu;
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void pair_exact_kernel(
     int64_t isamp = -1;
     int n = 0;
     if (tid < PS) {  // (wavefront 0)
-        if (p0 + tid < N) {
+        if (p0 + tid < NA) {
             isamp = order2[p0 + tid];
             slots = cand[isamp];
 #pragma unroll
@@ -510,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void pair_exact_kernel(
         const int r = L / XCH, cp = L % XCH;
         xchunk[u] = cp ^ ((r >> XSH) & (XCH - 1));
         int64_t p = p0 + r;
-        p = p < N ? p : N - 1;
+        p = p < NA ? p : NA - 1;
         xsrc[u] = X + (int64_t)order2[p] * ldx;
     }
     const int nkt = (d + KP - 1) / KP;

@@ -1155,6 +1155,9 @@ def test_refinement_at_the_edges_of_its_shapes(N, d, M, kind):
         fi = HipBackend(algorithm="filtered").load(X)
         fi.refine = 1
         fi.sweep_planes = planes
+        # (experimental, off by default: the distance of a sample the refinement decided evaluated inside
+        #  the sums kernel of the epoch -- segsum_dist_kernel; the same bits)
+        fi.defer = planes == 2
         for e in range(2):
             re_ = ex.epoch(W, hop, 1.0, 1e-3, "aligned", True)
             rf = fi.epoch(W, hop, 1.0, 1e-3, "aligned", True)

@@ -34,12 +34,13 @@ for name in args or ["c2"]:
     hop = bench.lattice_hops(rows, cols)
     sigma = 0.2 * np.sqrt(M)
     results = {}
-    variants = [("refine=0", algo, 0), ("refine=1", algo, 1), ("refine=2", algo, 2)]
+    variants = [("refine=0", algo, 0), ("refine=1", algo, 1), ("refine=1 d1", algo, 1), ("refine=2", algo, 2)]
     if with_exact:
         variants.append(("exact", "exact", False))
     for label, alg, refine in variants:
         hip = HipBackend(0, algorithm=alg)
         hip.refine = refine
+        hip.defer = label.endswith("d1")
         hip.load_device(X)
         hip.set_weights(W)
         for _ in range(4):
@@ -66,7 +67,7 @@ for name in args or ["c2"]:
                 pairs, ok, ovf, nun = hip.refine_counts()
                 extra += (f" | pairs/sample {pairs / n:.3f} refined {ok} of {(n + 127) // 128} overflow samples {ovf} "
                           f"distinct candidates per 64 samples {nun / ((n + 63) // 64):.1f}")
-        print(f"{name} {label:9s} {ms:8.3f} ms/epoch  phases " + " ".join(f"{v:.3f}" for v in ph) + extra, flush=True)
+        print(f"{name} {label:11s} {ms:8.3f} ms/epoch  phases " + " ".join(f"{v:.3f}" for v in ph) + extra, flush=True)
         results[label] = (res.winners.copy(), res.distances.copy(), res.new_weights.copy())
         hip.release()
     ref = results["refine=0"]

@@ -19,6 +19,9 @@ n, d, rows, cols, seed, kind, _ = bench.WORKLOADS[name]
 M = rows * cols
 dev = torch.device("cuda", 0)
 hip = HipBackend(0, algorithm=algo)
+for opt in sys.argv[4:]:   # e.g. refine=1 defer=0 sweep_planes=4
+    k, v = opt.split("=")
+    hip._set(k, int(v))
 X = bench.make_shard(torch, n, d, seed, dev, 0, kind)
 if name in bench.BF16_WORKLOADS:
     X = X.to(torch.bfloat16)
