@@ -2389,6 +2389,7 @@ struct FilterWs {
     int64_t *rbest;    // N: the refinement's best prototype per sample (bucket key of the pair kernel)
     int32_t *order2;   // N: the samples bucketed by it
     int32_t *ovf;      // 2 N: (sample, workgroup) of the samples whose candidates overflowed
+    uint16_t *ovf_cand;  // OV_CAP records of OV_REC: [count | candidates] of the first of them (refine.h)
     uint8_t *gflag;    // nb: 1 = refined (pair kernel); 0 = subset_exact_kernel's
     unsigned long long *rf_ctr;  // RF_CTR counters of the refinement (behind sched_ctr, zeroed with it)
     uint32_t *rf_qlen;           // [4]: lengths of the two class queues, of the overflow list, - (zeroed with it)
@@ -2418,6 +2419,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     const size_t o24 = take((size_t)2 * nb * 4);
     const size_t o25 = take((size_t)N * 8), o26 = take((size_t)N * 4), o27 = take((size_t)N * 8);
     const size_t o22 = take((size_t)N * 8), o23 = take((size_t)nb);
+    const size_t o29 = take((size_t)(N < OV_CAP ? N : OV_CAP) * OV_REC * 2);
     const int64_t Mg = (M + 63) / 64 * 64;
     const size_t o20 = take(M <= PRUNE_MAX_M ? (size_t)Mg * Mg * 4 : 0);
     const size_t o21 = take((size_t)nb * 4);
@@ -2425,6 +2427,7 @@ static size_t carve_filter(FilterWs *f, char *base, int64_t N, int64_t d, int64_
     if (f) {
         f->retry = (int32_t *)(base + o21);
         f->nnub = (uint32_t *)(base + o28);
+        f->ovf_cand = (uint16_t *)(base + o29);
         f->cand = (unsigned long long *)(base + o22); f->gflag = (uint8_t *)(base + o23);
         f->rbest = (int64_t *)(base + o25); f->order2 = (int32_t *)(base + o26); f->ovf = (int32_t *)(base + o27);
         f->rf_ctr = (unsigned long long *)(base + o17 + (size_t)SCHED_CTR * 4);
@@ -2823,7 +2826,7 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
     hipLaunchKernelGGL((refine_i8_kernel<NJ_, JT_>), dim3((unsigned)((f.nb + 7) / 8 * 8 < (WGS) ? (f.nb + 7) / 8 * 8 : (WGS))), dim3(NJ_ * 256), 0, s, \
                        xb.planes, xb.scale, xb.res16, xx_dev, N, (int)d, dpad, f.wt, (int)f.Mpad, f.wscale, ww_dev,    \
                        f.summary, order_dev, f.ulist, (int)f.Mpad, f.ucount, f.rf_queue + (size_t)(CLS) * f.nb,      \
-                       f.rf_qlen + (CLS), f.cand, f.rbest, f.rf_ctr, f.ovf, f.rf_qlen + 2, defer_M, idx_dev, dist_dev)
+                       f.rf_qlen + (CLS), f.cand, f.rbest, f.rf_ctr, f.ovf, f.rf_qlen + 2, f.ovf_cand, defer_M, idx_dev, dist_dev)
         static const int wgs_env = [] {   // DBGSOM_REFINE_WGS: workgroups per launch (diagnostics; a multiple of 8)
             const char *e = getenv("DBGSOM_REFINE_WGS");
             return e ? atoi(e) / 8 * 8 : 0;
@@ -2855,11 +2858,11 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         //  row walks slowed the sort and the pair kernel by more than it takes)
         if (x_dtype == DBGSOM_F32)
             hipLaunchKernelGGL((overflow_exact_kernel<float>), dim3(512), dim3(256), 0, s, (const float *)X_dev, (int)d, ldx,
-                               xx_dev, W_dev, ww_dev, f.ulist, (int)f.Mpad, f.ucount, f.ovf, f.rf_qlen + 2, round_f32,
+                               xx_dev, W_dev, ww_dev, f.ulist, (int)f.Mpad, f.ucount, f.ovf, f.rf_qlen + 2, f.ovf_cand, round_f32,
                                idx_dev, dist_dev);
         else
             hipLaunchKernelGGL((overflow_exact_kernel<double>), dim3(512), dim3(256), 0, s, (const double *)X_dev, (int)d, ldx,
-                               xx_dev, W_dev, ww_dev, f.ulist, (int)f.Mpad, f.ucount, f.ovf, f.rf_qlen + 2, round_f32,
+                               xx_dev, W_dev, ww_dev, f.ulist, (int)f.Mpad, f.ucount, f.ovf, f.rf_qlen + 2, f.ovf_cand, round_f32,
                                idx_dev, dist_dev);
     }
 #define DBGSOM_SUBSET_W(JTL, NWV_, STREAM)                                                        \

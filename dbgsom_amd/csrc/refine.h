@@ -35,6 +35,8 @@ constexpr int RF_SEGS = 2;            // tile-sized segments a candidate list ma
 constexpr int RF_MAX_PAIRS = 512;     // pairs per 128-sample workgroup of the pair kernel (two per lane)
 constexpr int RF_HASH = 512;          // slots of its table of distinct candidates
 constexpr unsigned long long RF_NONE = 0xffffffffffffffffull;  // four empty slots (prototype ids are < 0xffff)
+constexpr int OV_REC = 32;            // uint16 per record of an overflowing sample: [count | up to 31 candidates]
+constexpr int OV_CAP = 1 << 17;       // records (samples beyond: the whole list, as with count 0)
 
 // Workgroups are dealt to the 8 XCDs round robin (b % 8), each XCD with an L2 of its own.  Neighbouring
 // 128- / 64-sample workgroups share their prototypes (samples arrive bucketed): give every XCD a contiguous
@@ -69,8 +71,8 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
     const uint32_t *__restrict__ ucount, const int32_t *__restrict__ queue, const uint32_t *__restrict__ queue_len,
     unsigned long long *__restrict__ cand, int64_t *__restrict__ rbest, unsigned long long *__restrict__ rf_ctr,
-    int32_t *__restrict__ ovf, uint32_t *__restrict__ ovf_len, int defer_M, int64_t *__restrict__ idx_out,
-    double *__restrict__ dist_out) {
+    int32_t *__restrict__ ovf, uint32_t *__restrict__ ovf_len, uint16_t *__restrict__ ovf_cand, int defer_M,
+    int64_t *__restrict__ idx_out, double *__restrict__ dist_out) {
     // defer_M > 0 (= M; FilteredCall::defer_dist): a sample left with ONE candidate has its winner -- written
     // here with dist = -1, evaluated by the caller on its own pass over the rows -- and leaves the pair
     // kernel's work (bucket key M: behind every real bucket); only the undecided samples are bucketed.
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     float g_m = INFINITY, g_v[RF_SEGS * RF_C];
     int g_best = (int)list_all[0], g_n = 0, g_id[RF_SEGS * RF_C];
     bool g_ovf = false;
+    int g_k = -1, g_rc = 0;  // this sample's record of overflowing candidates (index, entries so far)
 #pragma unroll
     for (int e = 0; e < RF_SEGS * RF_C; ++e) { g_v[e] = 0.f; g_id[e] = 0xffff; }
     for (int seg = 0; seg < nseg; ++seg) {
@@ -132,8 +135,12 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     }
     // W (k-tile-major, the chunks of a row already swizzled by ITS index): op ow = u NW + wave, block
     // ow % (ROWS / 16), plane ow / (ROWS / 16); the row lands at its list position l
+    // (16-row blocks behind the end of the list are not fetched: their LDS rows keep whatever they held, and
+    //  nothing reads the v_ij of a row >= cnt; w_ops = this wavefront's live instructions, the same every k-tile)
     const int8_t *wsrc[C::W_OPS];
     int wdst[C::W_OPS];
+    bool wlive[C::W_OPS];
+    int w_ops = 0;
 #pragma unroll
     for (int u = 0; u < C::W_OPS; ++u) {
         constexpr int NBLK = C::ROWS / 16;
@@ -142,7 +149,10 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         const int j = (int)list[l < cnt ? l : cnt - 1];
         wsrc[u] = wplanes + pl * wps + (size_t)j * FKT + (((lane & 3) ^ ((l >> 2) & 3) ^ ((j >> 2) & 3)) << 4);
         wdst[u] = 2 * C::X_PLANE + pl * C::W_PLANE + blk * 1024;
+        wlive[u] = 16 * blk < cnt;
+        w_ops += wlive[u] ? 1 : 0;
     }
+    w_ops = __builtin_amdgcn_readfirstlane(w_ops);
     const int nkt = dpad / FKT;
     int i_kt = 0, i_stage = 0;
     auto issue = [&]() {
@@ -150,9 +160,18 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
 #pragma unroll
         for (int u = 0; u < C::X_OPS; ++u) fdma16(xsrc[u] + (size_t)i_kt * FKT, stage + xdst[u]);
 #pragma unroll
-        for (int u = 0; u < C::W_OPS; ++u) fdma16(wsrc[u] + (size_t)i_kt * w_rows * FKT, stage + wdst[u]);
+        for (int u = 0; u < C::W_OPS; ++u)
+            if (wlive[u]) fdma16(wsrc[u] + (size_t)i_kt * w_rows * FKT, stage + wdst[u]);
         i_stage = (i_stage == (FSTAGES - 1) * C::STAGE) ? 0 : i_stage + C::STAGE;
         ++i_kt;
+    };
+    auto wait_tile = [&]() {  // all but this wavefront's youngest tile have landed (s_waitcnt needs an immediate)
+        static_assert(C::W_OPS <= 4, "cases of wait_tile");
+        if (w_ops == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::X_OPS) : "memory");
+        else if (w_ops == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::X_OPS + 1) : "memory");
+        else if (w_ops == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::X_OPS + 2) : "memory");
+        else if (w_ops == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::X_OPS + 3) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::X_OPS + 4) : "memory");
     };
     // fragment offsets (bytes inside a stage; chunk (2 ks + lh) ^ swz = (2 ks) ^ (lh ^ swz))
     int xoff, woff[JT];
@@ -160,12 +179,14 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         const int r = wi * 32 + lc;
         xoff = r * FKT + ((lh ^ ((r >> 2) & 3)) * 16);
     }
+    // (the 32-entry tiles of the list are dealt to the NJ parts round robin -- tile jt NJ + wj -- so that a short
+    //  list keeps every wavefront busy: 136 entries in a 256-row tile are 3 + 2 tiles, not 4 + 1)
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
-        const int r = wj * 32 * JT + jt * 32 + lc;
+        const int r = (jt * NJ + wj) * 32 + lc;
         woff[jt] = 2 * C::X_PLANE + r * FKT + ((lh ^ ((r >> 2) & 3)) * 16);
     }
-    const int njt = min(JT, (cnt - wj * 32 * JT + 31) / 32);  // list tiles of this wavefront that hold entries
+    const int njt = min(JT, ((cnt + 31) / 32 - wj + NJ - 1) / NJ);  // list tiles of this wavefront that hold entries
     v16i_t acc[JT][3];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt)
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     if (nkt > 1) issue();
     int r_stage = 0;
     for (int t = 0; t < nkt; ++t) {
-        if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::OPS) : "memory");
+        if (t + 1 < nkt) wait_tile();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -211,7 +232,7 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         const double s_i = sx[order[p]];
         // (the lane's first list row, made opaque here: left visible, the 48 JT table / output addresses are
         //  hoisted out of the queue loop, kept across the matrix loop and spilled)
-        int lb = wj * 32 * JT + 4 * lh;
+        int lb = wj * 32 + 4 * lh;
         asm volatile("" : "+v"(lb));
         const double *ty = tab_y + lb, *tc = tab_c + lb;
         float *vcol = vm + lb * 128 + col;
@@ -220,7 +241,7 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
             if (jt < njt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int lo = jt * 32 + 8 * (r >> 2) + (r & 3);
+                    const int lo = jt * NJ * 32 + 8 * (r >> 2) + (r & 3);
                     const double T = ((double)acc[jt][0][r] * 256.0 + (double)acc[jt][1][r]) * 256.0 + (double)acc[jt][2][r];
                     vcol[lo * 128] = (float)(ty[lo] - s_i * (tc[lo] * T));
                     // (four values at a time: left to itself the scheduler converts all 16 JT accumulators first)
@@ -305,8 +326,26 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
                 }
                 n += nq;
             }
-            if (n > RF_C) g_ovf = true;
-            g_n += n < RF_C ? n : RF_C;
+            if (n > RF_C) {
+                // more than the slots hold: ALL of this segment's candidates go to the sample's record for
+                // overflow_exact_kernel (the segment's v_ij are in LDS now; same test as above)
+                g_ovf = true;
+                if (g_k < 0) g_k = (int)atomicAdd(ovf_len, 1u);
+                if ((uint32_t)g_k < (uint32_t)OV_CAP) {
+                    float m = INFINITY;
+#pragma unroll
+                    for (int q = 0; q < SP; ++q) m = fminf(m, pm[q * 128 + sidx]);
+                    const double thr = (double)m + eps2 + 2.4e-7 * (fabs((double)m) + eps2);
+                    uint16_t *rec = ovf_cand + (size_t)g_k * OV_REC;
+                    for (int l = 0; l < cnt; ++l)
+                        if (!((double)vm[l * 128 + sidx] > thr)) {
+                            if (g_rc < OV_REC - 1) rec[1 + g_rc] = list[l];
+                            ++g_rc;
+                        }
+                }
+            } else {
+                g_n += n;
+            }
         }
     }
     }  // (segments)
@@ -327,12 +366,25 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
                 ++n;
             }
         }
-        if (n > RF_C || g_ovf) {  // too many to keep apart: the whole list, exactly, by overflow_exact_kernel
+        if (n > RF_C || g_ovf) {  // too many to keep apart: exactly, by overflow_exact_kernel
             slots = RF_NONE;
             atomicAdd(rf_ctr + 2, 1ull);
-            const uint32_t k = atomicAdd(ovf_len, 1u);
-            ovf[2 * (size_t)k] = (int32_t)isamp;
-            ovf[2 * (size_t)k + 1] = group;
+            if (g_k < 0) g_k = (int)atomicAdd(ovf_len, 1u);
+            ovf[2 * (size_t)g_k] = (int32_t)isamp;
+            ovf[2 * (size_t)g_k + 1] = group;
+            if ((uint32_t)g_k < (uint32_t)OV_CAP) {
+                // the record: the candidates of the segments that overflowed (written there), then those of
+                // the others (registers, against the minimum of the whole list); more than it holds: count 0
+                // = the workgroup's whole list
+                uint16_t *rec = ovf_cand + (size_t)g_k * OV_REC;
+#pragma unroll
+                for (int z = 0; z < RF_SEGS * RF_C; ++z)
+                    if (z < g_n && !((double)g_v[z] > thr)) {
+                        if (g_rc < OV_REC - 1) rec[1 + g_rc] = (uint16_t)g_id[z];
+                        ++g_rc;
+                    }
+                rec[0] = (uint16_t)(g_rc < OV_REC ? g_rc : 0);
+            }
             n = 0;
         }
         int64_t key = (int64_t)g_best;  // bucket key of the pair kernel: any prototype does, the likely winner is best
@@ -651,15 +703,24 @@ __global__ __launch_bounds__(256, 2) void pair_exact_kernel(
     }
 }
 
-// ---- samples whose candidates did not fit RF_C slots: their workgroup's whole list, exactly -------------
-// (rare -- duplicated prototypes, a collapsed map, rows the bound says nothing about; one 256-thread
-// workgroup per sample, a few of them walking the queue; thread = list entry, the chain in plain loops)
+// ---- samples whose candidates did not fit RF_C slots --------------------------------------------------
+// (rare -- duplicated prototypes, a collapsed map, rows the bound says nothing about.)  One 256-thread
+// workgroup per sample, a few of them walking the queue.
+//   record count m > 0: the sample's m <= 31 candidates (refine_i8_kernel left them): lane r of the first
+//     wavefront runs the chain of candidate r; the rows come through LDS in chunks of 128 doubles, fetched by
+//     the whole workgroup in 16-byte pieces one chunk ahead (row pitch 1040 bytes: the 16 lanes of a
+//     ds_read_b128 group hit 16 different 4-bank sets), the sample's chunk beside them, widened.
+//   count 0 (a list in segments, more candidates than a record holds, a record beyond OV_CAP): the workgroup's
+//     whole list, thread = list entry, plain loops -- 16 KB of prototype row per entry straight from memory.
+constexpr int OV_KC = 128, OV_PITCH = OV_KC * 8 + 16;
 template <typename XT>
-__global__ __launch_bounds__(256) void overflow_exact_kernel(
+__global__ __launch_bounds__(256, 2) void overflow_exact_kernel(
     const XT *__restrict__ X, int d, int64_t ldx, const double *__restrict__ xx, const double *__restrict__ W,
     const double *__restrict__ ww, const uint16_t *__restrict__ ulist, int ulist_stride,
     const uint32_t *__restrict__ ucount, const int32_t *__restrict__ ovf, const uint32_t *__restrict__ ovf_len,
-    int round_f32, int64_t *__restrict__ idx_out, double *__restrict__ dist_out) {
+    const uint16_t *__restrict__ ovf_cand, int round_f32, int64_t *__restrict__ idx_out,
+    double *__restrict__ dist_out) {
+    __shared__ __attribute__((aligned(16))) char tile[2][(OV_REC) * OV_PITCH];  // row OV_REC - 1: the sample's chunk
     __shared__ double sv[256];
     __shared__ int sj[256];
     const int tid = threadIdx.x;
@@ -667,25 +728,89 @@ __global__ __launch_bounds__(256) void overflow_exact_kernel(
     for (uint32_t e = blockIdx.x; e < qn; e += gridDim.x) {
         const int64_t i = ovf[2 * (size_t)e];
         const int group = ovf[2 * (size_t)e + 1];
-        const int cnt = (int)ucount[group];
-        const uint16_t *list = ulist + (size_t)group * ulist_stride;
         const XT *x = X + i * ldx;
+        const uint16_t *rec = ovf_cand + (size_t)e * OV_REC;
+        const int m = e < (uint32_t)OV_CAP ? (int)rec[0] : 0;
         Best<1> best;
         best.init();
-        for (int l = tid; l < cnt; l += 256) {  // (ascending per thread)
-            const int j = (int)list[l];
-            const double *w = W + (int64_t)j * d;
-            double acc = 0.0;
-            for (int k = 0; k < d; k += 16) {  // (d % 16 == 0; the loads of a block first)
-                double wv[16], xv[16];
+        if (m > 0) {
+            // pieces of a chunk: piece q = tid + 256 u -> candidate q / 64, 16 bytes q % 64 of its 1024
+            constexpr int NP = (OV_REC - 1) * 64 / 256 + 1;
+            const double *src[NP];
+            int dst[NP];
+            bool live[NP];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { wv[u] = w[k + u]; xv[u] = widen(x[k + u]); }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) acc = fma(wv[u], xv[u], acc);
+            for (int u = 0; u < NP; ++u) {
+                const int q = tid + 256 * u, r = q >> 6, part = q & 63;
+                live[u] = r < m;
+                const int j = (int)rec[1 + (live[u] ? r : 0)];
+                src[u] = W + (int64_t)j * d + 2 * part;
+                dst[u] = r * OV_PITCH + 16 * part;
             }
-            double rv = (xx[i] + (-2.0 * acc)) + ww[j];
-            if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
-            best.push(rv, j);
+            d2_t stage[NP];
+            double xs = 0.0;
+            const int nkc = (d + OV_KC - 1) / OV_KC;
+            auto fetch = [&](int kc) {
+                const int k0 = kc * OV_KC;
+#pragma unroll
+                for (int u = 0; u < NP; ++u)
+                    if (live[u]) {
+                        const int k = k0 + 2 * ((tid + 256 * u) & 63);   // (d % 16 == 0: a piece is inside the row or behind it)
+                        stage[u] = k < d ? *reinterpret_cast<const d2_t *>(src[u] + k0) : d2_t{0.0, 0.0};
+                    }
+                if (tid < OV_KC) xs = k0 + tid < d ? widen(x[k0 + tid]) : 0.0;
+            };
+            auto put = [&](int buf) {
+#pragma unroll
+                for (int u = 0; u < NP; ++u)
+                    if (live[u]) *reinterpret_cast<d2_t *>(tile[buf] + dst[u]) = stage[u];
+                if (tid < OV_KC) *reinterpret_cast<double *>(tile[buf] + (OV_REC - 1) * OV_PITCH + 8 * tid) = xs;
+            };
+            const bool mine = tid < m;
+            double acc = 0.0;
+            fetch(0);
+            put(0);
+            __syncthreads();
+            for (int kc = 0; kc < nkc; ++kc) {
+                if (kc + 1 < nkc) fetch(kc + 1);
+                if (mine) {  // (zeros behind column d: fma(0, 0, acc) == acc)
+                    const char *row = tile[kc & 1] + tid * OV_PITCH;
+                    const char *xr = tile[kc & 1] + (OV_REC - 1) * OV_PITCH;
+#pragma unroll 8
+                    for (int u = 0; u < OV_KC / 2; ++u) {
+                        const d2_t wv = *reinterpret_cast<const d2_t *>(row + 16 * u);
+                        const d2_t xv = *reinterpret_cast<const d2_t *>(xr + 16 * u);
+                        acc = fma(wv[0], xv[0], acc);
+                        acc = fma(wv[1], xv[1], acc);
+                    }
+                }
+                if (kc + 1 < nkc) put((kc + 1) & 1);
+                __syncthreads();
+            }
+            if (mine) {
+                const int j = (int)rec[1 + tid];
+                double rv = (xx[i] + (-2.0 * acc)) + ww[j];
+                if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
+                best.push(rv, j);
+            }
+        } else {
+            const int cnt = (int)ucount[group];
+            const uint16_t *list = ulist + (size_t)group * ulist_stride;
+            for (int l = tid; l < cnt; l += 256) {  // (ascending per thread)
+                const int j = (int)list[l];
+                const double *w = W + (int64_t)j * d;
+                double acc = 0.0;
+                for (int k = 0; k < d; k += 16) {  // (d % 16 == 0; the loads of a block first)
+                    double wv[16], xv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { wv[u] = w[k + u]; xv[u] = widen(x[k + u]); }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc = fma(wv[u], xv[u], acc);
+                }
+                double rv = (xx[i] + (-2.0 * acc)) + ww[j];
+                if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
+                best.push(rv, j);
+            }
         }
         sv[tid] = best.v[0];
         sj[tid] = best.j[0];

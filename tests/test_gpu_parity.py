@@ -427,6 +427,24 @@ def test_full_size_properties(hip, o):
     p = perm.cpu().numpy()
     assert np.array_equal(i2, win[p]) and np.array_equal(d2, dist[p])
     hip.release()
+    # (5) the filtered search against the all-pairs search on the FULL arrays (k = 1 and k = 2), and the
+    # whole epoch's new prototypes
+    from dbgsom_amd.backend import HipBackend
+
+    ex = HipBackend(algorithm="exact")
+    ex.load_device(X)
+    fi = HipBackend(algorithm="filtered")
+    fi.load_device(X)
+    re_, rf = (b.epoch(W, hop, 0.2 * np.sqrt(M), gamma, "compact", True) for b in (ex, fi))
+    assert fi.filter_log[-1][0] == "filtered" and not ex.filter_log   # (what ran)
+    assert np.array_equal(re_.winners, rf.winners) and np.array_equal(re_.distances, rf.distances)
+    assert np.array_equal(re_.winners, win) and np.array_equal(re_.distances, dist)
+    assert np.array_equal(re_.new_weights, rf.new_weights)
+    de, ie = ex.bmu(W, 2)
+    df, if_ = fi.bmu(W, 2)
+    assert np.array_equal(ie, if_) and np.array_equal(de, df)
+    ex.release()
+    fi.release()
 
 
 def test_device_reductions_f2_f3(hip, o):
@@ -1102,7 +1120,8 @@ def test_refined_search_is_identical_to_exact(o, dt, planes):
     X = X.astype(np.float64) if dt == "f64" else X
     W = X[rng.choice(N, M, replace=False)].astype(np.float64)
     W[11] = W[5]                                      # a tie: the lower index wins
-    W[40:47] = W[39]                                  # seven copies: more candidates than slots
+    W[40:47] = W[39]                                  # seven copies: more candidates than slots (the overflow
+    W[100:140] = W[99]                                # kernel on their record); 41: more than a record (whole list)
     storage = "bf16" if dt == "bf16" else None
     ex = HipBackend(algorithm="exact").load(X, storage=storage)
     fi = HipBackend(algorithm="filtered").load(X, storage=storage)
@@ -1131,6 +1150,7 @@ def test_refined_search_is_identical_to_exact(o, dt, planes):
         W = np.nan_to_num(re_.new_weights)
         W[11] = W[5]
         W[40:47] = W[39]
+        W[100:140] = W[99]
     assert saw_overflow, "the duplicated prototypes must exercise the overflow kernel"
     ex.release(); fi.release()
 
