@@ -44,6 +44,13 @@ constexpr int OV_CAP = 1 << 17;       // records (samples beyond: the whole list
 // that is a multiple of 8; the order only decides who runs where.
 __device__ __forceinline__ int xcd_group(int b, int n_groups8) { return (b & 7) * (n_groups8 >> 3) + (b >> 3); }
 
+// the least float32 that is >= t (a NaN stays a NaN: every comparison with it fails, everything is kept)
+__device__ __forceinline__ float f32_at_least(double t) {
+    float f = (float)t;
+    if ((double)f < t) f = __uint_as_float(f >= 0.f ? __float_as_uint(f) + 1u : __float_as_uint(f) - 1u);
+    return f;
+}
+
 template <int NJ, int JT>
 struct RefineCfg {
     static constexpr int NW = 4 * NJ;          // wavefronts: 4 (32 samples each) x NJ (parts of the list)
@@ -55,7 +62,8 @@ struct RefineCfg {
     static constexpr int MAIN = RING > VM ? RING : VM;
     static constexpr int OFF_TAB = MAIN;       // |w_j|^2 and 2 t_j / F16^2 of the list entries
     static constexpr int OFF_MISC = OFF_TAB + ROWS * 16;
-    static constexpr int BYTES = OFF_MISC + 64;
+    static constexpr int OFF_META = OFF_MISC + 64;   // per sample: 2 eps_i, s_i (doubles), its index (int32)
+    static constexpr int BYTES = OFF_META + 128 * 20;
     static constexpr int X_OPS = 16 / NW;            // LDS-DMA instructions per wavefront and k-tile
     static constexpr int W_OPS = (ROWS / 8) / NW;
     static constexpr int OPS = X_OPS + W_OPS;
@@ -63,6 +71,17 @@ struct RefineCfg {
     static constexpr int MAX_CNT = ROWS;
 };
 
+#ifndef REFINE_DEPHASE
+#define REFINE_DEPHASE 1
+#endif
+#ifndef REFINE_STAMPS
+#define REFINE_STAMPS 0   // experiment builds: phase times (s_memtime ticks, 100 MHz) of a few workgroups via printf
+#endif
+#if REFINE_STAMPS & 1
+#define R_STAMP(k) do { if (tid == 0) r_st[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define R_STAMP(k)
+#endif
 template <int NJ, int JT>
 __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx, const double *__restrict__ xres,
@@ -82,6 +101,8 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     __shared__ __attribute__((aligned(16))) char smem[C::BYTES];
     double *tab_y = reinterpret_cast<double *>(smem + C::OFF_TAB), *tab_c = tab_y + C::ROWS;
     uint32_t *misc = reinterpret_cast<uint32_t *>(smem + C::OFF_MISC);  // [8] pairs of this workgroup
+    double *eps_s = reinterpret_cast<double *>(smem + C::OFF_META), *sx_s = eps_s + 128;
+    int32_t *isamp_s = reinterpret_cast<int32_t *>(sx_s + 128);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave & 3, wj = wave >> 2;
@@ -91,11 +112,21 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     const int per_xcd = (qn + 7) / 8, q_lo = (int)(blockIdx.x & 7) * per_xcd, q_hi = min(qn, q_lo + per_xcd);
     const int q_first = q_lo + (int)(blockIdx.x >> 3), q_step = (int)(gridDim.x >> 3);
     if ((int)(blockIdx.x >> 3) >= q_step) return;  // (a grid that is no multiple of 8: the odd workgroups have no part)
+    // (the loads a workgroup's set-up hangs on are taken out of its way: the NEXT entry's group and list length
+    //  are fetched while this one runs; the set-up itself issues what needs one round trip -- list entries,
+    //  sample indices -- then the first two tiles' DMAs, and only then what needs a second: norms, scales)
+    int group_next = q_first < q_hi ? queue[q_first] : 0;
+    int cnt_next = (int)ucount[group_next];
     for (int entry = q_first; entry < q_hi; entry += q_step) {
     if (entry != q_first) __syncthreads();  // the previous workgroup's tables are done with
-    const int group = queue[entry];
+#if REFINE_STAMPS & 1
+    uint64_t r_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    R_STAMP(0);
+    const int group = __builtin_amdgcn_readfirstlane(group_next);
     const int64_t p0 = (int64_t)group * 128;
-    const int cnt_all = __builtin_amdgcn_readfirstlane((int)ucount[group]);  // 1 <= cnt_all <= RF_SEGS ROWS (class_fill_kernel)
+    const int cnt_all = __builtin_amdgcn_readfirstlane(cnt_next);  // 1 <= cnt_all <= RF_SEGS ROWS (class_fill_kernel)
+    if (entry + q_step < q_hi) group_next = queue[entry + q_step];
     const uint16_t *list_all = ulist + (size_t)group * ulist_stride;
     // A list longer than the tile (a workgroup whose samples come from two clusters: 4 % of the C5 shard's) is
     // taken in segments of ROWS entries, each a pass over the planes of its own; a sample's candidates of
@@ -113,11 +144,11 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     const uint16_t *list = list_all + seg * C::ROWS;
     const int cnt = min(C::ROWS, cnt_all - seg * C::ROWS);
     if (tid < 10 && seg == 0) misc[tid] = 0u;
-    for (int l = tid; l < C::ROWS; l += C::NW * 64) {
-        const int j = (int)list[l < cnt ? l : cnt - 1];
-        tab_y[l] = ww[j];
-        tab_c[l] = 2.0 * tw[j] / (F16 * F16);
-    }
+    static_assert(C::ROWS <= C::NW * 64, "one table entry per thread");
+    const int tj = tid < C::ROWS ? (int)list[tid < cnt ? tid : cnt - 1] : 0;          // (first hop)
+    int64_t p_me = p0 + (tid & 127);
+    p_me = p_me < N ? p_me : N - 1;
+    const int i_me = (seg == 0 && tid < 128) ? order[p_me] : 0;                          // (first hop)
     // ---- DMA sources ------------------------------------------------------------------------------
     // X: op o = u NW + wave, row block o % 8 (16 rows), plane o / 8; lane -> row 16 block + lane / 4,
     // LDS chunk lane % 4 holds the row's chunk (lane % 4) ^ swz(row) (the image the fragments read)
@@ -130,7 +161,11 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         const int r = 16 * blk + (lane >> 2);
         int64_t p = p0 + r;
         p = p < N ? p : N - 1;
+#if REFINE_STAMPS & 2   // timing experiment: every workgroup streams the same 128 sample rows (L2 hits; results are wrong)
+        xsrc[u] = xplanes + pl * xps + (size_t)r * dpad + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+#else
         xsrc[u] = xplanes + pl * xps + (size_t)order[p] * dpad + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+#endif
         xdst[u] = pl * C::X_PLANE + blk * 1024;
     }
     // W (k-tile-major, the chunks of a row already swizzled by ITS index): op ow = u NW + wave, block
@@ -195,15 +230,37 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[jt][lv][r] = 0;
 
+    R_STAMP(1);
     issue();
     if (nkt > 1) issue();
+    {   // second hop, under the DMAs in flight: the tables of the list entries, the samples' constants
+        double ty = 0.0, tc = 0.0, xv = 0.0, rx = 0.0, sv = 0.0;
+        if (tid < C::ROWS) { ty = ww[tj]; tc = tw[tj]; }
+        if (seg == 0 && tid < 128) { xv = xx[i_me]; rx = xres[i_me]; sv = sx[i_me]; }
+        if (tid < C::ROWS) {
+            tab_y[tid] = ty;
+            tab_c[tid] = 2.0 * tc / (F16 * F16);
+        }
+        if (seg == 0 && tid < 128) {
+            const double yy_max = summary[2], rw = summary[3];
+            const double xn = sqrt(xv) * (1.0 + 1e-9), wn = sqrt(yy_max) * (1.0 + 1e-9);
+            const double rounding = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xv + yy_max);
+            eps_s[tid] = 2.0 * (2.0 * (rx * (wn + rw) + xn * rw) * (1.0 + 1e-9) + rounding);
+            sx_s[tid] = sv;
+            isamp_s[tid] = i_me;
+        }
+    }
     int r_stage = 0;
     for (int t = 0; t < nkt; ++t) {
         if (t + 1 < nkt) wait_tile();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < nkt) issue();
+        // (the two wavefronts of a SIMD -- wave w and w + 4 -- take turns: one issues its LDS-DMAs of tile
+        //  t + 2 in front of its matrix products, the other behind them, so that the one's issue stalls run
+        //  under the other's products instead of both stalling right behind the barrier)
+        const bool issue_first = REFINE_DEPHASE == 0 || NJ < 2 || (wj & 1) == 0;
+        if (issue_first && t + 2 < nkt) issue();
         const char *stage = smem + r_stage;
         r_stage = (r_stage == (FSTAGES - 1) * C::STAGE) ? 0 : r_stage + C::STAGE;
 #pragma unroll
@@ -222,14 +279,15 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
                 }
             }
         }
+        if (!issue_first && t + 2 < nkt) issue();
     }
+    R_STAMP(2);
     __syncthreads();  // every wavefront is done with the ring: v_ij takes its place
     float *vm = reinterpret_cast<float *>(smem);
     {
         const int col = wi * 32 + lc;
-        int64_t p = p0 + col;
-        p = p < N ? p : N - 1;
-        const double s_i = sx[order[p]];
+        const double s_i = sx_s[col];
+        if (seg == nseg - 1 && entry + q_step < q_hi) cnt_next = (int)ucount[group_next];  // (its first hop is long back)
         // (the lane's first list row, made opaque here: left visible, the 48 JT table / output addresses are
         //  hoisted out of the queue loop, kept across the matrix loop and spilled)
         int lb = wj * 32 + 4 * lh;
@@ -251,6 +309,7 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         }
     }
     __syncthreads();
+    R_STAMP(3);
     {
         // selection: SP threads per sample, each over a contiguous part of the list (parts in list order, so
         // that candidates come out ascending); scratch behind the v_ij matrix, inside the ring's bytes
@@ -266,44 +325,55 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         if (act) {
             float m = INFINITY;
             int lm = l0;
-#pragma unroll 4
-            for (int l = l0; l < l1; ++l) {  // (a NaN never becomes the minimum)
-                const float v = vm[l * 128 + sidx];
-                if (v < m) { m = v; lm = l; }
+            // (eight LDS reads in flight at a time: one after the other, a read's latency per list entry)
+            for (int lb8 = l0; lb8 < l1; lb8 += 8) {  // (a NaN never becomes the minimum)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = vm[min(lb8 + u, l1 - 1) * 128 + sidx];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (lb8 + u < l1 && v[u] < m) { m = v[u]; lm = lb8 + u; }
             }
             pm[part * 128 + sidx] = m;
             plm[part * 128 + sidx] = lm;
         }
+        R_STAMP(6);
         __syncthreads();
         double eps2 = 0.0;
         if (act) {
-            const int64_t isamp = order[p0 + sidx];
-            const double yy_max = summary[2], rw = summary[3], xv = xx[isamp], rx = xres[isamp];
-            const double xn = sqrt(xv) * (1.0 + 1e-9), wn = sqrt(yy_max) * (1.0 + 1e-9);
-            const double rounding = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xv + yy_max);
-            eps2 = 2.0 * (2.0 * (rx * (wn + rw) + xn * rw) * (1.0 + 1e-9) + rounding);
+            eps2 = eps_s[sidx];
             float m = INFINITY;
 #pragma unroll
             for (int q = 0; q < SP; ++q) m = fminf(m, pm[q * 128 + sidx]);  // (fminf passes over a NaN)
             // v <= min + 2 eps, with both sides' rounding to float32 on the safe side; a NaN anywhere keeps
             const double thr = (double)m + eps2 + 2.4e-7 * (fabs((double)m) + eps2);
+            const float thr_f = f32_at_least(thr);   // (compared in float32: a bound >= thr keeps at least as many)
             int n = 0;
             unsigned long long slots = RF_NONE;
             uint32_t pos = 0u;
-#pragma unroll 4
-            for (int l = l0; l < l1; ++l) {
-                if (!((double)vm[l * 128 + sidx] > thr)) {
-                    if (n < RF_C) {
-                        slots = (slots & ~(0xffffull << (16 * n))) | ((unsigned long long)list[l] << (16 * n));
-                        pos |= (uint32_t)l << (8 * n);
+            for (int lb8 = l0; lb8 < l1; lb8 += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = vm[min(lb8 + u, l1 - 1) * 128 + sidx];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int l = lb8 + u;
+                    if (l < l1 && !(v[u] > thr_f)) {
+                        if (n < RF_C) {
+                            slots = (slots & ~(0xffffull << (16 * n))) | ((unsigned long long)list[l] << (16 * n));
+                            pos |= (uint32_t)l << (8 * n);
+                        }
+                        ++n;
                     }
-                    ++n;
                 }
             }
             psl[part * 128 + sidx] = slots;
             ppos[part * 128 + sidx] = pos;
             pn[part * 128 + sidx] = n;
         }
+        R_STAMP(7);
         __syncthreads();
         if (act && part == 0) {  // this segment's candidates (ascending) behind those of the earlier ones
             int n = 0;
@@ -335,13 +405,20 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
                     float m = INFINITY;
 #pragma unroll
                     for (int q = 0; q < SP; ++q) m = fminf(m, pm[q * 128 + sidx]);
-                    const double thr = (double)m + eps2 + 2.4e-7 * (fabs((double)m) + eps2);
+                    const float thr_f = f32_at_least((double)m + eps2 + 2.4e-7 * (fabs((double)m) + eps2));
                     uint16_t *rec = ovf_cand + (size_t)g_k * OV_REC;
-                    for (int l = 0; l < cnt; ++l)
-                        if (!((double)vm[l * 128 + sidx] > thr)) {
-                            if (g_rc < OV_REC - 1) rec[1 + g_rc] = list[l];
-                            ++g_rc;
-                        }
+                    for (int lb8 = 0; lb8 < cnt; lb8 += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = vm[min(lb8 + u, cnt - 1) * 128 + sidx];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (lb8 + u < cnt && !(v[u] > thr_f)) {
+                                if (g_rc < OV_REC - 1) rec[1 + g_rc] = list[lb8 + u];
+                                ++g_rc;
+                            }
+                    }
                 }
             } else {
                 g_n += n;
@@ -349,13 +426,11 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         }
     }
     }  // (segments)
+    R_STAMP(4);
     if (tid < 128 && p0 + tid < N) {
         // the candidates of all segments against the minimum of the whole list
-        const int64_t isamp = order[p0 + tid];
-        const double yy_max = summary[2], rw = summary[3], xv = xx[isamp], rx = xres[isamp];
-        const double xn = sqrt(xv) * (1.0 + 1e-9), wn = sqrt(yy_max) * (1.0 + 1e-9);
-        const double rounding = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xv + yy_max);
-        const double eps2 = 2.0 * (2.0 * (rx * (wn + rw) + xn * rw) * (1.0 + 1e-9) + rounding);
+        const int64_t isamp = isamp_s[tid];
+        const double eps2 = eps_s[tid];
         const double thr = (double)g_m + eps2 + 2.4e-7 * (fabs((double)g_m) + eps2);
         int n = 0;
         unsigned long long slots = RF_NONE;
@@ -406,6 +481,14 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         atomicAdd(rf_ctr + 0, (unsigned long long)misc[8]);
         atomicAdd(rf_ctr + 1, 1ull);
     }
+#if REFINE_STAMPS & 1
+    R_STAMP(5);
+    if (tid == 0 && (blockIdx.x % 97) == 3)
+        printf("refine<%d,%d> wg %d entry %d cnt %d: setup %d loop %d vm %d select %d (min %d mark %d merge %d) final %d  (ticks)\n", NJ, JT,
+               (int)blockIdx.x, entry, cnt_all, (int)(r_st[1] - r_st[0]), (int)(r_st[2] - r_st[1]), (int)(r_st[3] - r_st[2]),
+               (int)(r_st[4] - r_st[3]), (int)(r_st[6] - r_st[3]), (int)(r_st[7] - r_st[6]), (int)(r_st[4] - r_st[7]),
+               (int)(r_st[5] - r_st[4]));
+#endif
     }  // (queue)
 }
 
