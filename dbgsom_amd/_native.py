@@ -97,6 +97,7 @@ SIGNATURES = {
     "dbgsom_ctx_partition": (_ci, [_vp, _vp, _i64, _ci, _vp, _vp]),
     "dbgsom_ctx_subset_create": (_ci, [_vp, _i64, ctypes.POINTER(_vp)]),
     "dbgsom_ctx_epoch_info": (_ci, [_vp, _vp]),
+    "dbgsom_ctx_arm_ms": (_ci, [_vp, _vp]),
     "dbgsom_ctx_filter_counts": (_ci, [_vp, _vp, _i64]),
     "dbgsom_ctx_refine_counts": (_ci, [_vp, _vp]),
     "dbgsom_ctx_phase_ms": (_ci, [_vp, _vp]),

@@ -212,7 +212,9 @@ class HipBackend(HotPathBackend):
     FILTER_MIN_PROTOTYPES = 129
     FILTER_MAX_MEAN_CANDIDATES = 320
     FILTER_MIN_QUERY_ROWS = 32768
-    # cost model of the adaptive digit planes (mirrors engine.hip; tests recompute the choice)
+    # the PRIOR of the engine's search policy (engine.hip: adapt_arms): what an arm that has never been timed is
+    # priced at; arms that have run clean are compared by the engine's clock (arm_ms()).  Mirrored here only for
+    # the test of the prior on small inputs, where every epoch copies results to the host and nothing is timed.
     SWEEP_COST = {1: 0.35, 2: 1.0, 3: 1.96}
     LIST_COST = 12.5
     PRUNE_PASS_COST = 60.0
@@ -563,6 +565,12 @@ class HipBackend(HotPathBackend):
         info = (ctypes.c_double * 8)()
         _native.call("dbgsom_ctx_epoch_info", self._ctx, info)
         return [float(v) for v in info]
+
+    def arm_ms(self):
+        """dbgsom_ctx_arm_ms: {(seeds, planes): ms} of the arms of the search policy that have been timed."""
+        ms = (ctypes.c_double * 12)()
+        _native.call("dbgsom_ctx_arm_ms", self._ctx, ms)
+        return {(i // 4, i % 4): float(v) for i, v in enumerate(ms) if v == v}
 
     def _log_epoch(self):
         info = self.epoch_info()

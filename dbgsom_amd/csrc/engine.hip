@@ -239,17 +239,22 @@ struct dbgsom_ctx {
     int timing = 0;
     int use_graph = 0;
     // per-sample refinement in front of the exact stage (filter.hip 2d): 0 = off, 1 = on, 2 = by measurement
-    // (the exact stage of the first training epochs of a map size is timed with and without it -- HIP
-    // events on the stream -- and the faster form kept; re-measured when the lists change by a quarter)
+    // (per arm of the search policy, once it has settled on the arm: the first training epochs are timed with and
+    // without it -- wall clock of the whole blocking epoch call, best of two -- and the faster form kept;
+    // measured again when the arm's lists change by a quarter)
     int refine = 2;
-    double rf_ms[2] = {NAN, NAN};   // epoch (wall clock of the blocking call) without / with the refinement: best of two
-    int rf_n[2] = {0, 0};
+    struct RefineTimes {
+        double ms[2] = {NAN, NAN};  // epoch without / with the refinement: best of two
+        int n[2] = {0, 0};
+        double mean_ref = NAN;      // the lists these were measured on
+    };
+    RefineTimes rf[12];             // [4 seeds + planes]
+    int rf_arm = 0;                 // the arm of the running call
     int defer = 0;                  // with the refinement: distances of decided samples inside the sums kernel
                                     // (experimental, off: one chain wavefront per CU cannot keep up -- NOTES.md)
     bool last_deferred = false;
     int last_round_f32 = 0;
     int64_t rf_M = -1;
-    double rf_mean_ref = NAN;
     int rf_measuring = -1;          // the form the running call is timing (-1: none)
     bool last_refined = false;
     bool last_k2_filtered = false;  // the last k = 2 search went through the pruning form
@@ -295,6 +300,12 @@ struct dbgsom_ctx {
     double arm_known[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};  // [seeds][planes]
     double arm_seen[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};   // last result ever
     int arm_age[3][4] = {};   // updates of the map since the arm last ran
+    // measured: wall clock (ms) of the blocking epoch call when the arm last ran WITHOUT anything riding along (a
+    // counting-only launch, re-seeding passes, the refinement's own measurements, results copied to the host);
+    // two arms that both have one are compared by it, the cost model only prices arms that have none
+    double arm_ms[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};
+    double last_epoch_ms = NAN;     // of the epoch update_policy is looking at (NaN: not a clean measurement)
+    int arm_duels[3][4] = {};       // clean epochs an arm was given only to be timed
     int arm_wait[3][4] = {{16, 16, 16, 16}, {16, 16, 16, 16}, {16, 16, 16, 16}};
     bool last_frozen = false;
     int plane_hold = 0;
@@ -502,18 +513,27 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     if (mean_known) rf_rows = (int)(c->last_mean * 1.25 + 8.0);
     bool use_refine = c->refine == 1;
     c->rf_measuring = -1;
+    c->rf_arm = 4 * (prev_idx ? 2 : (c->last_seed_full ? 1 : 0)) + c->planes_used;
     if (c->refine == 2 && mean_known) {
-        if (c->rf_M != M || !(fabs(c->last_mean - c->rf_mean_ref) <= 0.25 * c->rf_mean_ref)) {
-            c->rf_M = M; c->rf_mean_ref = c->last_mean; c->rf_ms[0] = c->rf_ms[1] = NAN; c->rf_n[0] = c->rf_n[1] = 0;
+        if (c->rf_M != M) {
+            c->rf_M = M;
+            for (auto &r : c->rf) r = dbgsom_ctx::RefineTimes();
         }
+        dbgsom_ctx::RefineTimes &r = c->rf[c->rf_arm];
+        // (the lists of THIS arm: what it left the last time it ran, else what the last epoch had)
+        const double arm_mean = c->arm_known[c->rf_arm >> 2][c->rf_arm & 3];
+        const double lists = arm_mean == arm_mean ? arm_mean : c->last_mean;
+        if (!(fabs(lists - r.mean_ref) <= 0.25 * r.mean_ref)) { r = dbgsom_ctx::RefineTimes(); r.mean_ref = lists; }
         // prior (what has not been measured is not tried blind): the refinement reads two digit planes and the
         // rows once more whatever the lists are -- short lists, few features or a few workgroups never pay;
         // lists beyond twice its largest tile stay the matrix-core stage's anyway
-        const bool eligible = c->last_mean >= 24.0 && c->last_mean <= 400.0 && s.dp >= 256 && s.N >= 65536;
+        const bool eligible = lists >= 24.0 && lists <= 400.0 && s.dp >= 256 && s.N >= 65536;
+        // timed only on an arm the policy has settled on (or the caller fixed): two forms of the SAME search
+        const bool settled = c->sweep_planes != 0 || c->plane_hold > 0;
         if (!eligible) use_refine = false;
-        else if (may_probe && c->rf_n[0] < 2) { use_refine = false; c->rf_measuring = 0; }
-        else if (may_probe && c->rf_n[1] < 2) { use_refine = true; c->rf_measuring = 1; }
-        else use_refine = c->rf_n[0] >= 2 && c->rf_n[1] >= 2 && c->rf_ms[1] < c->rf_ms[0];
+        else if (may_probe && settled && r.n[0] < 2) { use_refine = false; c->rf_measuring = 0; }
+        else if (may_probe && settled && r.n[1] < 2) { use_refine = true; c->rf_measuring = 1; }
+        else use_refine = r.n[0] >= 2 && r.n[1] >= 2 && r.ms[1] < r.ms[0];
     }
     call.refine_rows = use_refine ? rf_rows : 0;
     c->last_refined = use_refine;
@@ -618,6 +638,8 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
         c->planeM = M;
         for (auto &r : c->arm_known) for (double &k : r) k = NAN;
         for (auto &r : c->arm_seen) for (double &k : r) k = NAN;
+        for (auto &r : c->arm_ms) for (double &k : r) k = NAN;
+        for (auto &r : c->arm_duels) for (int &k : r) k = 0;
         for (auto &r : c->arm_wait) for (int &k : r) k = 16;
         c->plane_hold = 0;
     }
@@ -637,12 +659,40 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
     const bool remeasured = !isnan(c->arm_seen[row][p]);
     c->arm_known[row][p] = c->arm_seen[row][p] = mean;
     c->arm_age[row][p] = 0;
+    if (!isnan(c->last_epoch_ms))   // (the mean of the last two looks: one epoch's clock jitters by a few per cent)
+        c->arm_ms[row][p] = isnan(c->arm_ms[row][p]) ? c->last_epoch_ms : 0.5 * (c->arm_ms[row][p] + c->last_epoch_ms);
     if (c->last_probed) {  // what arm 0 would have produced from the same seeds
         c->arm_known[row][0] = c->arm_seen[row][0] = c->last_probe_mean;
         c->arm_age[row][0] = 0;
     }
+    auto allowed = [&](int s_, int q) {
+        if (c->sweep_planes && q != (c->sweep_planes == 4 ? 0 : c->sweep_planes)) return false;  // fixed by the caller
+        if (q == 0 && M > PRUNE_MAX_M) return false;
+        if (row == 2) return s_ == 2;                                      // hinted: only the planes vary
+        return s_ == 0 || (s_ == 1 && c->seed_stride == 0);               // a caller's stride: cheap seeds only
+    };
     if (c->plane_hold > 0) {
         c->best_mean = mean;
+        // A contender the model prices within a factor of two of this arm and that has never run clean: one epoch
+        // of it, on its own, and the clock decides between the two (once per arm until it ages out).
+        if (!isnan(c->arm_ms[row][p])) {
+            int ds = -1, dq = -1;
+            double dc = 2.0 * (fixed(row, p) + LIST_COST * mean);
+            for (int s_ = 0; s_ < 3; ++s_)
+                for (int q = 0; q <= 3; ++q)
+                    if (allowed(s_, q) && !(s_ == row && q == p) && !isnan(c->arm_known[s_][q]) &&
+                        isnan(c->arm_ms[s_][q]) && c->arm_duels[s_][q] < 1) {
+                        const double cst = fixed(s_, q) + LIST_COST * c->arm_known[s_][q];
+                        if (cst < dc) { dc = cst; ds = s_; dq = q; }
+                    }
+            if (ds >= 0) {
+                ++c->arm_duels[ds][dq];
+                c->seed_mode = ds == 1 ? 1 : 0;
+                c->planes_next = dq;
+                c->plane_hold = 0;
+                return;
+            }
+        }
         if (--c->plane_hold == 0) {
             // The alternatives get another look once the map has moved on: an arm whose sweep /
             // pre-pass costs LESS than the current one after arm_wait (16, doubling up to 128 every
@@ -652,23 +702,31 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
                 for (int q = 0; q <= 3; ++q) {
                     if ((s_ == row && q == p) || isnan(c->arm_known[s_][q])) continue;
                     const int wait = fixed(s_, q) < fixed(row, p) ? c->arm_wait[s_][q] : 128;
-                    if (c->arm_age[s_][q] >= wait) c->arm_known[s_][q] = NAN;
+                    if (c->arm_age[s_][q] >= wait) { c->arm_known[s_][q] = c->arm_ms[s_][q] = NAN; c->arm_duels[s_][q] = 0; }
                 }
         }
         return;
     }
-    auto allowed = [&](int s_, int q) {
-        if (c->sweep_planes && q != (c->sweep_planes == 4 ? 0 : c->sweep_planes)) return false;  // fixed by the caller
-        if (q == 0 && M > PRUNE_MAX_M) return false;
-        if (row == 2) return s_ == 2;                                      // hinted: only the planes vary
-        return s_ == 0 || (s_ == 1 && c->seed_stride == 0);               // a caller's stride: cheap seeds only
-    };
-    int bs = row, bp = p;
-    double bc = fixed(row, p) + LIST_COST * mean;
+    // An arm that has been timed costs what it took; the model prices the others.  Both in the model's units: the
+    // timed arms give the units per millisecond (geometric mean of model cost / time over them).
+    double log_sum = 0.0;
+    int n_timed = 0;
     for (int s_ = 0; s_ < 3; ++s_)
         for (int q = 0; q <= 3; ++q)
-            if (allowed(s_, q) && !isnan(c->arm_known[s_][q])) {
-                const double cst = fixed(s_, q) + LIST_COST * c->arm_known[s_][q];
+            if (!isnan(c->arm_known[s_][q]) && c->arm_ms[s_][q] > 0.0) {
+                log_sum += log((fixed(s_, q) + LIST_COST * c->arm_known[s_][q]) / c->arm_ms[s_][q]);
+                ++n_timed;
+            }
+    const double per_ms = n_timed ? exp(log_sum / n_timed) : NAN;
+    auto priced = [&](int s_, int q, double lists) {
+        return c->arm_ms[s_][q] > 0.0 ? c->arm_ms[s_][q] * per_ms : fixed(s_, q) + LIST_COST * lists;
+    };
+    int bs = row, bp = p;
+    double bc = priced(row, p, mean);
+    for (int s_ = 0; s_ < 3; ++s_)
+        for (int q = 0; q <= 3; ++q)
+            if (allowed(s_, q) && !isnan(c->arm_known[s_][q]) && !(s_ == row && q == p)) {
+                const double cst = priced(s_, q, c->arm_known[s_][q]);
                 if (cst < bc) { bc = cst; bs = s_; bp = q; }
             }
     // unknown arms worth a look, cheapest optimistic cost first
@@ -992,7 +1050,7 @@ int dbgsom_ctx_set_option(dbgsom_ctx *c, const char *name, int64_t v) {
     } else if (!strcmp(name, "refine")) {
         DBGSOM_REQUIRE(v >= 0 && v <= 2, "refine must be 0 (off), 1 (on) or 2 (by measurement)");
         c->refine = (int)v;
-        c->rf_ms[0] = c->rf_ms[1] = NAN; c->rf_n[0] = c->rf_n[1] = 0;
+        for (auto &r : c->rf) r = dbgsom_ctx::RefineTimes();
     } else if (!strcmp(name, "filter_min_query_rows")) {
         DBGSOM_REQUIRE(v >= 0, "filter_min_query_rows must be >= 0");
         c->filter_min_query_rows = v;
@@ -1078,7 +1136,8 @@ static void reset_training_state(dbgsom_ctx *c) {
     c->sumsM = 0;
     // the resident prototypes were laid out for the old samples' padded row length: gone with them
     c->M = c->otherM = 0;
-    c->rf_M = -1; c->rf_ms[0] = c->rf_ms[1] = NAN; c->rf_n[0] = c->rf_n[1] = 0;
+    c->rf_M = -1;
+    for (auto &r : c->rf) r = dbgsom_ctx::RefineTimes();
 }
 
 int dbgsom_ctx_load(dbgsom_ctx *c, const void *X_host, int x_dtype, int64_t N, int64_t d, int storage) {
@@ -1395,10 +1454,14 @@ int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f
         if (rc != DBGSOM_OK && rc != DBGSOM_ERANGE) break;
         if (measuring >= 0) {   // wall clock of the blocking call behind the upload of W: BMU + sums + smoothing
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-            c->rf_ms[measuring] = c->rf_n[measuring] == 0 ? ms : fmin(ms, c->rf_ms[measuring]);
-            ++c->rf_n[measuring];
+            dbgsom_ctx::RefineTimes &r = c->rf[c->rf_arm];
+            r.ms[measuring] = r.n[measuring] == 0 ? ms : fmin(ms, r.ms[measuring]);
+            ++r.n[measuring];
         }
         c->last_frozen = (flags & DBGSOM_EPOCH_FROZEN) != 0;
+        c->last_epoch_ms = (c->last_filtered && !c->last_probed && measuring < 0 && !W_new_host && !idx_host && !dist_host)
+                               ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()
+                               : NAN;
         update_policy(c, c->tail.as<double>()[2 * M + 2], c->tail.as<double>()[2 * M + 3], c->tail.as<double>()[2 * M + 4],
                       (s.N + 127) / 128, M);
     } while (0);
@@ -1679,6 +1742,14 @@ int dbgsom_ctx_epoch_info(dbgsom_ctx *c, double *info8) {
     info8[5] = (double)c->plane_hold;
     info8[6] = c->last_filtered && c->last_probed ? c->last_probe_mean : NAN;
     info8[7] = c->last_filtered && c->last_seed_full ? 1.0 : 0.0;
+    return DBGSOM_OK;
+}
+
+int dbgsom_ctx_arm_ms(dbgsom_ctx *c, double *ms12) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(ms12, "null pointer");
+    for (int s_ = 0; s_ < 3; ++s_)
+        for (int q = 0; q < 4; ++q) ms12[4 * s_ + q] = c->arm_ms[s_][q];
     return DBGSOM_OK;
 }
 

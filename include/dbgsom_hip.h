@@ -407,6 +407,11 @@ int dbgsom_ctx_subset_create(dbgsom_ctx *ctx, int64_t neuron, dbgsom_ctx **child
  *          hold, mean list length a counting-only pruning launch found beside the sweep (NaN: none
  *          ran), stateless seeds came from the full pre-pass (0/1)] of the last epoch */
 int dbgsom_ctx_epoch_info(dbgsom_ctx *ctx, double *info8);
+/* what the engine's search policy has measured: ms12[4 * seeds + planes] = wall clock (ms) of the epoch call
+ * when that arm last ran with nothing riding along (seeds 0 = cheap pre-pass, 1 = full pre-pass, 2 = previous
+ * winners; planes 0 = triangle pruning, 1 .. 3 = digit planes of the sweep; NaN: not timed / aged out).  Two
+ * timed arms are compared by these, the cost model prices the others (engine.hip: adapt_arms). */
+int dbgsom_ctx_arm_ms(dbgsom_ctx *ctx, double *ms12);
 /* candidate-list length per 128-sample workgroup of the last filtered search (n = ceil(N/128)) */
 int dbgsom_ctx_filter_counts(dbgsom_ctx *ctx, uint32_t *counts_host, int64_t n);
 /* dbgsom_bmu_filtered_refine_counts of the context's last filtered search */

@@ -908,6 +908,65 @@ def test_adaptive_digit_planes_settle_on_the_cheaper_sweep(o):
         assert used[-1] == min(seen, key=lambda p: be.plane_cost(p, seen[p], M))
 
 
+def test_search_arms_that_have_been_timed_are_compared_by_their_time():
+    """The arm policy (engine.hip: adapt_arms) prices an arm it has never run by the cost model, but two
+    arms that both ran clean -- nothing riding along, nothing copied to the host -- are compared by the
+    measured wall clock of the epoch call (dbgsom_ctx_arm_ms).  Mid-clustered data (six clusters, lists of
+    ~170 prototypes): the arm the policy settles on is, among the arms it tried, the fastest by the
+    engine's own clock and within a tolerance the fastest by this test's (each arm forced on a fresh
+    context).  Results are those of the all-pairs search whatever runs."""
+    import time
+
+    from dbgsom_amd.backend import RESIDENT, HipBackend
+
+    rng = np.random.default_rng(21)
+    N, d, rows, cols = 160_000, 256, 32, 32
+    M = rows * cols
+    c = rng.normal(size=(6, d)).astype(np.float32) * 4
+    X = c[rng.integers(0, 6, N)] + rng.normal(size=(N, d)).astype(np.float32)
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    hop = gi.lattice_hops(rows, cols)
+
+    arms = []
+
+    def frozen(be, n):
+        out = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            be.epoch(RESIDENT, hop, 2.0, 1e-3, "compact", False, keep_on_device=True, frozen=True)
+            out.append((time.perf_counter() - t0) * 1e3)
+            info = be.epoch_info()
+            arms.append((1 if info[7] else 0, int(info[2])))                     # (seeds, planes) of the epoch
+        return out
+
+    be = HipBackend(algorithm="filtered").load(X)
+    be.set_weights(W)
+    frozen(be, 24)
+    tried, timed = list(arms), be.arm_ms()
+    assert be._get("plane_hold") > 0 and tried[-1] == tried[-2] == tried[-3], (tried, timed)   # settled
+    assert len(timed) >= 2, (timed, tried)                                       # a comparison by the clock took place
+    settled = tried[-1]
+    stateless = {a: t for a, t in timed.items() if a[0] != 2}
+    assert settled in stateless and stateless[settled] <= 1.03 * min(stateless.values()), (settled, timed)
+    lists = {e[2]: e[1] for e in be.filter_log if e[0] == "filtered"}
+    assert 100 <= lists[0] <= 320, lists                                          # (the data the test is about)
+    # the same arms, each forced, by this test's clock
+    mine = {}
+    for planes in sorted({a[1] for a in stateless}):
+        fb = HipBackend(algorithm="filtered").load(X)
+        fb.sweep_planes = planes if planes else 4
+        fb.set_weights(W)
+        mine[planes] = float(np.median(frozen(fb, 7)[2:]))
+        fb.release()
+    assert mine[settled[1]] <= 1.15 * min(mine.values()), (settled, mine, timed)
+    # and the answers are the all-pairs kernel's
+    r = be.epoch(RESIDENT, hop, 2.0, 1e-3, "compact", True, keep_on_device=True, frozen=True)
+    ex = HipBackend(algorithm="exact").load(X)
+    q = ex.epoch(W, hop, 2.0, 1e-3, "compact", True)
+    assert np.array_equal(r.winners, q.winners) and np.array_equal(r.distances, q.distances)
+    be.release(); ex.release()
+
+
 def test_eight_wavefront_sweep_and_prepass_still_agree_with_the_all_pairs_kernel():
     """The 4-wavefront kernels are the default shape of the one-product sweep and of the seed
     pre-pass; the 8-wavefront ones (DBGSOM_SWEEP_SHAPE=8 / DBGSOM_PREPASS_SHAPE=8, read once per
