@@ -35,12 +35,18 @@ for case in range(n_cases):
     W = X[rng.choice(N, M, replace=M > N)].astype(np.float64)
     if rng.random() < 0.3:
         W = W + rng.normal(size=W.shape) * 1e-3
+    if rng.random() < 0.4:   # runs of identical prototypes: ties, more inseparable candidates than the refinement's slots
+        for _ in range(int(rng.integers(1, 6))):
+            a, k = int(rng.integers(0, M - 1)), int(rng.integers(2, 48))
+            W[a:a + k] = W[int(rng.integers(0, M))]
     hop = np.zeros((M, M))
     storage = "bf16" if dt == "bf16" else None
     ex = HipBackend(algorithm="exact").load(X, storage=storage)
     fi = HipBackend(algorithm="filtered_hint" if rng.random() < 0.5 else "filtered").load(X, storage=storage)
     fi.seed_stride = int(rng.choice([0, 1, 2, 8, 32]))
     fi.sweep_planes = int(rng.choice([0, 1, 2, 3, 4, 4]))
+    if len(sys.argv) > 3 and sys.argv[3] == "refine":   # the per-sample refinement in half of the cases
+        fi.refine = int(rng.random() < 0.5)
     print(f"case {case:3d} N={N} d={d} M={M} {kind} {dt} ...", flush=True)
     ok = True
     for e in range(2):
@@ -68,8 +74,9 @@ for case in range(n_cases):
                       "d exact", re_.distances[i], "d filt", rf.distances[i], "d oracle", od, flush=True)
         W = np.nan_to_num(re_.new_weights)   # dead neurons of the aligned layout are NaN rows
     c = fi.filter_counts()
+    rc = fi.refine_counts() if fi.refined else None
     print(f"case {case:3d} N={N:6d} d={d:5d} M={M:5d} {kind:8s} {dt:4s} {fi.algorithm:13s} stride={fi.seed_stride:2d} "
-          f"planes={fi.sweep_planes} lists mean {c.mean():7.1f} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+          f"planes={fi.sweep_planes} lists mean {c.mean():7.1f} refined {rc} -> {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += not ok
     ex.release(); fi.release()
 print(f"{n_cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
