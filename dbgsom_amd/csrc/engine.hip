@@ -943,10 +943,16 @@ int resident_bmu(dbgsom_ctx *c, const double *W_host, int64_t M, int k, int roun
                             hint ? c->acc_ws.as<int32_t>() : nullptr, c->qidx.as<int64_t>(), c->qdist.as<double>());
     }
     // k = 2 (topographic error, BaseSom.py:945): through the pruning form of the filtered search when the
-    // training epochs have shown that it works on this data -- the last filtered search of this map size
-    // ran it (arm 0 of the policy: clustered data, lists a fraction of the map); otherwise all pairs
-    if (k == 2 && filter_applies(c, M) && M <= PRUNE_MAX_M && M >= 2 && c->last_filtered && c->planes_used == 0 &&
-        c->last_filter_M == M && c->last_mean == c->last_mean && c->last_mean <= (double)c->max_mean_candidates) {
+    // training epochs have shown that it works on this data -- arm 0 of the policy has run (or been counted)
+    // on this map size and left lists a fraction of the map (clustered data); otherwise all pairs
+    double lists0 = NAN;
+    if (c->planeM == M)
+        for (int r = 0; r < 3; ++r) {
+            const double v = c->arm_seen[r][0];
+            if (v == v && !(lists0 <= v)) lists0 = v;
+        }
+    if (k == 2 && filter_applies(c, M) && M <= PRUNE_MAX_M && M >= 2 && c->last_filter_M == M && lists0 == lists0 &&
+        lists0 <= (double)c->max_mean_candidates) {
         const bool hint = (c->algorithm == DBGSOM_ALG_AUTO || c->algorithm == DBGSOM_ALG_FILTERED_HINT) &&
                           c->hint_valid && c->hintM <= M;
         TRY(ensure_planes(c, s));
