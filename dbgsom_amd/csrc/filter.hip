@@ -2489,6 +2489,7 @@ thread_local StageTimer g_timer;
 struct SideStream {
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t forked = nullptr, joined = nullptr, joined2 = nullptr, mid = nullptr;
+    hipEvent_t gap_fork = nullptr, gap_done = nullptr;   // the prototype gaps beside the seed pre-pass
     int state = 0;  // 0 untried, 1 ready, -1 unavailable
     int device = -1;
     bool ready() {
@@ -2506,7 +2507,9 @@ struct SideStream {
                      hipEventCreateWithFlags(&forked, hipEventDisableTiming) == hipSuccess &&
                      hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess &&
                      hipEventCreateWithFlags(&joined2, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&mid, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
+                     hipEventCreateWithFlags(&mid, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&gap_fork, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&gap_done, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
         }
         return state == 1 && dev == device;  // a thread that moved to another device: no fork
     }
@@ -2687,6 +2690,30 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
                        nkt_used < nkt_full ? f.kt_sel : (const int32_t *)nullptr, f.wt,
                        f.wt_sub, f.wscale, f.wl1, f.yy_part, f.wn0, f.wres16, f.tickets + 1, tables);
     g_timer.mark(1, s);
+    // The gaps between the prototypes (pruning form) need the digit planes of W and nothing of the samples:
+    // in a stateless search they are worked out on the second stream BESIDE the seed pre-pass and the bucket
+    // sort (one wavefront per 64 x 64 tile: a few hundred small workgroups next to a launch that fills the
+    // chip or, on a rank's share of the samples, does not), DBGSOM_GAP_FORK=0 keeps them in line
+    auto launch_gap = [&](hipStream_t gs) -> int {
+        const unsigned gt = (unsigned)(f.Mg / 64);
+        if (k2) DBGSOM_HIP_CHECK(hipMemsetAsync(f.nnub, 0x7f, (size_t)f.Mg * 4, gs));   // (0x7f7f7f7f: 3.4e38, "no bound")
+        hipLaunchKernelGGL(proto_gap_kernel, dim3(gt, gt), dim3(64), 0, gs, f.wt, (int)f.Mpad, dpad, (int)M, (int)d,
+                           f.wscale, f.wn0, ww_dev, f.gap, (int)f.Mg, k2 ? f.nnub : (uint32_t *)nullptr);
+        return DBGSOM_OK;
+    };
+    static const int gap_fork_env = [] {
+        const char *e = getenv("DBGSOM_GAP_FORK");
+        return e ? atoi(e) : 1;
+    }();
+    bool gap_aside = false;
+    if ((prune || prune_probe) && !prev_idx_dev && gap_fork_env != 0 && g_side.ready()) {
+        DBGSOM_HIP_CHECK(hipEventRecord(g_side.gap_fork, s));
+        DBGSOM_HIP_CHECK(hipStreamWaitEvent(g_side.stream, g_side.gap_fork, 0));
+        const int rc = launch_gap(g_side.stream);
+        if (rc != DBGSOM_OK) return rc;
+        DBGSOM_HIP_CHECK(hipEventRecord(g_side.gap_done, g_side.stream));
+        gap_aside = true;
+    }
     if (!prev_idx_dev) {
         // no previous winners: seed = arg-min of a coarser (3-product) sweep, then bucket the samples
         // the pre-pass is as coarse as the sweep it seeds: one product for the one-product sweep
@@ -2728,10 +2755,12 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
                        f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad,     \
                        f.ucount, (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr, f.sched_ctr)
     if (prune || prune_probe) {
-        const unsigned gt = (unsigned)(f.Mg / 64);
-        if (k2) DBGSOM_HIP_CHECK(hipMemsetAsync(f.nnub, 0x7f, (size_t)f.Mg * 4, s));   // (0x7f7f7f7f: 3.4e38, "no bound")
-        hipLaunchKernelGGL(proto_gap_kernel, dim3(gt, gt), dim3(64), 0, s, f.wt, (int)f.Mpad, dpad, (int)M, (int)d,
-                           f.wscale, f.wn0, ww_dev, f.gap, (int)f.Mg, k2 ? f.nnub : (uint32_t *)nullptr);
+        if (gap_aside) {
+            DBGSOM_HIP_CHECK(hipStreamWaitEvent(s, g_side.gap_done, 0));
+        } else {
+            const int rc = launch_gap(s);
+            if (rc != DBGSOM_OK) return rc;
+        }
         unsigned long long *sum = reinterpret_cast<unsigned long long *>(f.sched_ctr + SCHED_SUM) + (prune ? 0 : 1);
         unsigned long long *rlen = reinterpret_cast<unsigned long long *>(f.sched_ctr + SCHED_RETRY);
         const uint32_t retry_above = (uint32_t)(M / 8 > 96 ? M / 8 : 96);

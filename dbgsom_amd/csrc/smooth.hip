@@ -340,7 +340,10 @@ __global__ __launch_bounds__(256) void smooth_gemm_generic_kernel(const double *
 }
 
 // rowchg[i] = |W_i - W'_i|_2; with a split-K GEMM, W'_i is first put together from the pieces (in
-// piece order) and divided by den[i]
+// piece order) and divided by den[i].  One wavefront per row, four rows per workgroup (a quarter of the
+// tickets, no LDS tree per row: the launch took 28 us for 1024 rows of 784 with a workgroup per row); the
+// squares are added per lane in column order and across the lanes in a fixed butterfly.
+constexpr int RC_ROWS = 4;
 __global__ __launch_bounds__(256) void rowchange_kernel(const double *__restrict__ Wo,
                                                         double *__restrict__ Wn, int M, int d,
                                                         int splits, const double *__restrict__ part,
@@ -348,30 +351,28 @@ __global__ __launch_bounds__(256) void rowchange_kernel(const double *__restrict
                                                         double *__restrict__ rowchg,
                                                         uint32_t *__restrict__ ticket,
                                                         double *__restrict__ change_total) {
-    __shared__ double red[256];
-    const int i = blockIdx.x, t = threadIdx.x;
-    double s = 0.0;
-    const double dn = den[i];
-    for (int c = t; c < d; c += 256) {
-        double wn;
-        if (splits == 1) {
-            wn = Wn[(size_t)i * d + c];
-        } else {
-            double p = part[(size_t)i * d + c];
-            for (int z = 1; z < splits; ++z) p += part[((size_t)z * M + i) * d + c];
-            wn = p / dn;
-            Wn[(size_t)i * d + c] = wn;
+    const int t = threadIdx.x, lane = t & 63;
+    const int i = blockIdx.x * RC_ROWS + (t >> 6);
+    if (i < M) {
+        double s = 0.0;
+        const double dn = den[i];
+        for (int c = lane; c < d; c += 64) {
+            double wn;
+            if (splits == 1) {
+                wn = Wn[(size_t)i * d + c];
+            } else {
+                double p = part[(size_t)i * d + c];
+                for (int z = 1; z < splits; ++z) p += part[((size_t)z * M + i) * d + c];
+                wn = p / dn;
+                Wn[(size_t)i * d + c] = wn;
+            }
+            const double df = Wo[(size_t)i * d + c] - wn;
+            s += df * df;
         }
-        const double df = Wo[(size_t)i * d + c] - wn;
-        s += df * df;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) rowchg[i] = sqrt(s);
     }
-    red[t] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (t < w) red[t] += red[t + w];
-        __syncthreads();
-    }
-    if (t == 0) rowchg[i] = sqrt(red[0]);
     // change_total = sum_i rowchg[i]: the workgroup that finishes last adds them up, in the fixed
     // order of a 1024-leaf strided binary tree -- bitwise reproducible
     if (!last_workgroup_done(ticket, gridDim.x)) return;
@@ -426,7 +427,7 @@ int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, do
     else
         hipLaunchKernelGGL(smooth_gemm_generic_kernel, grid, dim3(256), 0, s, w.G, w.C, w.den, Mi, Mp, di, splits,
                            w.part, W_new);
-    hipLaunchKernelGGL(rowchange_kernel, dim3((unsigned)M), dim3(256), 0, s, W_old, W_new, Mi, di,
+    hipLaunchKernelGGL(rowchange_kernel, dim3((unsigned)((M + RC_ROWS - 1) / RC_ROWS)), dim3(256), 0, s, W_old, W_new, Mi, di,
                        splits, w.part, w.den, w.rowchg, w.ticket, change_total);
     return launch_status("smooth kernels");
 }

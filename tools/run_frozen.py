@@ -19,10 +19,17 @@ n, d, rows, cols, seed, kind, _ = bench.WORKLOADS[name]
 M = rows * cols
 dev = torch.device("cuda", 0)
 hip = HipBackend(0, algorithm=algo)
-for opt in sys.argv[4:]:   # e.g. refine=1 defer=0 sweep_planes=4
+take = 0
+for opt in sys.argv[4:]:   # e.g. refine=1 defer=0 sweep_planes=4; rows=125000: a rank's share of the workload
     k, v = opt.split("=")
-    hip._set(k, int(v))
+    if k == "rows":
+        take = int(v)
+    else:
+        hip._set(k, int(v))
 X = bench.make_shard(torch, n, d, seed, dev, 0, kind)
+if take:
+    X = X[:take].contiguous()
+    n = take
 if name in bench.BF16_WORKLOADS:
     X = X.to(torch.bfloat16)
 hip.load_device(X)
