@@ -20,10 +20,14 @@ ALG_AUTO, ALG_EXACT, ALG_FILTERED, ALG_FILTERED_HINT = 0, 1, 2, 3
 ALGORITHMS = {"auto": ALG_AUTO, "exact": ALG_EXACT, "filtered": ALG_FILTERED,
               "filtered_hint": ALG_FILTERED_HINT}
 EPOCH_FROZEN = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 # int (*)(void *user, double *buf_dev, int64_t count, void *stream)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                 ctypes.c_void_p)
+# dbgsom_collective_fn(user, op, buf_dev, count, stream): op 0 all-reduce, 1 reduce-scatter, 2 all-gather
+COLLECTIVE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                 ctypes.c_void_p)
+COLL_ALLREDUCE, COLL_REDUCE_SCATTER, COLL_ALLGATHER = 0, 1, 2
 CENTRES_COMPACT, CENTRES_ALIGNED = 0, 1
 LAYOUTS = {"compact": CENTRES_COMPACT, "aligned": CENTRES_ALIGNED}
 MAX_PROTOTYPES = 16000
@@ -72,6 +76,7 @@ SIGNATURES = {
     "dbgsom_ctx_set_labels": (_ci, [_vp, _vp, _i64]),
     "dbgsom_ctx_set_topology": (_ci, [_vp, _vp, _i64]),
     "dbgsom_ctx_set_allreduce": (_ci, [_vp, _vp, _vp]),
+    "dbgsom_ctx_set_collectives": (_ci, [_vp, _vp, _vp, _ci, _ci]),
     "dbgsom_rccl_unique_id": (_ci, [_vp]),
     "dbgsom_rccl_comm_init": (_ci, [_vp, _ci, _ci, ctypes.POINTER(_vp)]),
     "dbgsom_rccl_comm_destroy": (_ci, [_vp]),

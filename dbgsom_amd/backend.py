@@ -297,6 +297,10 @@ class HipBackend(HotPathBackend):
     # with the refinement: the distance of a sample it decided is evaluated inside the sums kernel of the
     # epoch (one pass over the float rows for distance and sums) -- 1 (default) / 0
     defer = property(lambda self: bool(self._get("defer")), lambda self, v: self._set("defer", int(bool(v))))
+    # neighbourhood smoothing sharded over the ranks (reduce-scatter of column blocks of the sums, all-gather of
+    # the new prototypes): 0 never, 1 whenever the collective can, 2 (default) on large maps
+    shard_smooth = property(lambda self: self._get("shard_smooth"), lambda self, v: self._set("shard_smooth", int(v)))
+    shard_epochs = property(lambda self: self._get("shard_epochs"))
     planes_cached = property(lambda self: bool(self._get("planes_cached")))
     padded_features = property(lambda self: self._get("padded_features"))
 
@@ -315,7 +319,7 @@ class HipBackend(HotPathBackend):
         rank, world = dist_info()
         force = os.environ.get("DBGSOM_FORCE_COLLECTIVE") == "1" and _group_is_up()
         if world == 1 and not force:
-            _native.call("dbgsom_ctx_set_allreduce", self._ctx, None, None)
+            _native.call("dbgsom_ctx_set_collectives", self._ctx, None, None, 0, 1)
             self._cb = None
             return
         import torch
@@ -342,34 +346,55 @@ class HipBackend(HotPathBackend):
             _native.call("dbgsom_ctx_set_rccl", self._ctx, comm)
             self._cb = None
             return
-        cache = {}   # the context reuses its stream and (until the map grows) its sums buffer
+        cache = {}   # the context reuses its stream and (until the map grows) its buffers
 
-        def reduce(_user, ptr, count, stream):
+        def collective(_user, op, ptr, count, stream):
+            """dbgsom_collective_fn: all-reduce of `count` values, or -- for the smoothing sharded over the
+            ranks -- reduce-scatter / all-gather in place over `world` blocks of `count` values."""
             try:
                 ext = cache.get(("stream", stream))
                 if ext is None:
                     ext = cache[("stream", stream)] = torch.cuda.ExternalStream(stream, device=dev)
+                total = count if op == _native.COLL_ALLREDUCE else count * world
                 with torch.cuda.stream(ext):
-                    t = cache.get((ptr, count))
+                    t = cache.get((ptr, total))
                     if t is None:
                         if len(cache) > 16:
                             cache.clear()
                             cache[("stream", stream)] = ext
-                        t = cache[(ptr, count)] = torch.as_tensor(_DeviceArray(ptr, count), device=dev)
-                    if on_device:
-                        td.all_reduce(t, op=td.ReduceOp.SUM)   # RCCL, ordered on the context's stream
+                        t = cache[(ptr, total)] = torch.as_tensor(_DeviceArray(ptr, total), device=dev)
+                    mine = t[rank * count:(rank + 1) * count] if op != _native.COLL_ALLREDUCE else None
+                    if on_device:   # RCCL through torch.distributed, ordered on the context's stream
+                        if op == _native.COLL_ALLREDUCE:
+                            td.all_reduce(t, op=td.ReduceOp.SUM)
+                        elif op == _native.COLL_REDUCE_SCATTER:
+                            td.reduce_scatter_tensor(mine, t, op=td.ReduceOp.SUM)
+                        else:
+                            td.all_gather_into_tensor(t, mine.clone())
                     else:  # gloo and friends: through the host (tests: several ranks on one GPU)
                         h = t.cpu()
-                        td.all_reduce(h, op=td.ReduceOp.SUM)
-                        t.copy_(h)
+                        if op == _native.COLL_ALLREDUCE:
+                            td.all_reduce(h, op=td.ReduceOp.SUM)
+                            t.copy_(h)
+                        elif op == _native.COLL_REDUCE_SCATTER:
+                            # (gloo has no reduce-scatter: a reduce per block to its owner -- every block is
+                            #  summed in one order, whoever owns it)
+                            for r in range(world):
+                                blk = h[r * count:(r + 1) * count]
+                                td.reduce(blk, dst=r, op=td.ReduceOp.SUM)
+                            mine.copy_(h[rank * count:(rank + 1) * count])
+                        else:
+                            parts = [torch.empty(count, dtype=h.dtype) for _ in range(world)]
+                            td.all_gather(parts, h[rank * count:(rank + 1) * count].contiguous())
+                            t.copy_(torch.cat(parts))
                         ext.synchronize()
                 return 0
             except BaseException as e:  # nothing may propagate through the C frames
                 self._cb_error = e
                 return 1
 
-        self._cb = _native.ALLREDUCE_FN(reduce)
-        _native.call("dbgsom_ctx_set_allreduce", self._ctx, self._cb, None)
+        self._cb = _native.COLLECTIVE_FN(collective)
+        _native.call("dbgsom_ctx_set_collectives", self._ctx, self._cb, None, rank, world)
 
     # -- a8: residency --------------------------------------------------------------------------
     def load(self, X, storage=None):

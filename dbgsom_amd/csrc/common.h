@@ -153,5 +153,15 @@ size_t smooth_workspace_bytes(int64_t M, int64_t d);
 int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, double sigma,
                   int layout, const double *W_old, double *W_new, double *change_total, void *ws,
                   size_t ws_bytes, hipStream_t s);
+// smoothing sharded over the ranks (smooth.hip): column blocks of cb = smooth_block_cols columns; one block
+// of the reduce-scatter buffer = [S block (M x cb) | K | a | E | status | pad] = smooth_block_elems values
+int64_t smooth_block_cols(int64_t d, int nranks);
+int64_t smooth_block_elems(int64_t M, int64_t d, int nranks);
+int launch_pack_blocks(const double *sums, int64_t M, int64_t d, int nranks, double *out, hipStream_t s);
+int launch_smooth_block(const double *S_b, const double *K, const double *a, int64_t M, int64_t cb, int64_t d_full,
+                        const float *hop, double sigma, int layout, double *Wb, void *ws, size_t ws_bytes,
+                        hipStream_t s);
+int launch_rowchange_blocks(const double *blocks, int64_t M, int64_t d, int64_t cb, const double *W_old, double *W_new,
+                            double *change_total, void *ws, hipStream_t s);
 
 }  // namespace dbgsom

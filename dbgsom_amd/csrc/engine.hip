@@ -324,6 +324,17 @@ struct dbgsom_ctx {
     void *allreduce_user = nullptr;
     void *rccl_comm = nullptr;
     bool rccl_owned = false;
+    // smoothing sharded over the ranks (columns of W'): the epoch's collective is then a reduce-scatter of column
+    // blocks of the sums and an all-gather of the W' blocks (smooth.hip).  shard_smooth: 0 = never, 1 = whenever
+    // the collective can do it, 2 = when the smoothing GEMM is large (default).  Needs rank / nranks: from the
+    // RCCL communicator, or from dbgsom_ctx_set_collectives.
+    dbgsom_collective_fn coll = nullptr;
+    void *coll_user = nullptr;
+    int coll_rank = 0, coll_nranks = 1;
+    int shard_smooth = 2;
+    bool sums_sharded = false;   // the last accumulate step left the reduced sums as this rank's block
+    int64_t shard_epochs = 0;    // epochs smoothed that way (diagnostics)
+    DevBuf shard_send, shard_gather;
     // traffic of the prototypes across PCIe (f-4 evidence: whole matrices only at the first epoch, at
     // growth steps and at the end of a fit)
     int64_t w_up_calls = 0, w_up_bytes = 0, w_down_calls = 0, w_down_bytes = 0, w_row_writes = 0, w_row_reads = 0;
@@ -554,6 +565,10 @@ struct RcclApi {
     int (*get_unique_id)(void *id) = nullptr;                                        // ncclGetUniqueId
     int (*comm_init_rank)(void **comm, int nranks, /* ncclUniqueId by value */ ...) = nullptr;
     int (*all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*reduce_scatter)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;   // (optional)
+    int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;            // (optional)
+    int (*comm_count)(void *, int *) = nullptr;                                                     // (optional)
+    int (*comm_user_rank)(void *, int *) = nullptr;                                                 // (optional)
     int (*comm_destroy)(void *) = nullptr;
     const char *(*error_string)(int) = nullptr;
     bool tried = false, ok = false;
@@ -583,6 +598,10 @@ int rccl_load() {
     g_rccl_init = (nccl_comm_init_rank_fn)dlsym(h, "ncclCommInitRank");
     g_rccl.all_reduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
     g_rccl.comm_destroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    g_rccl.reduce_scatter = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclReduceScatter");
+    g_rccl.all_gather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.comm_count = (int (*)(void *, int *))dlsym(h, "ncclCommCount");
+    g_rccl.comm_user_rank = (int (*)(void *, int *))dlsym(h, "ncclCommUserRank");
     g_rccl.error_string = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
     g_rccl.ok = g_rccl.get_unique_id && g_rccl_init && g_rccl.all_reduce && g_rccl.comm_destroy;
     if (!g_rccl.ok) { set_error("librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy"); return DBGSOM_ESTATE; }
@@ -594,6 +613,7 @@ void drop_rccl(dbgsom_ctx *c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         (void)g_rccl.comm_destroy(c->rccl_comm);
     }
+    if (c->rccl_comm) { c->coll_rank = 0; c->coll_nranks = 1; }
     c->rccl_comm = nullptr;
     c->rccl_owned = false;
 }
@@ -608,6 +628,15 @@ int run_allreduce(dbgsom_ctx *c, double *buf, int64_t count) {
         }
         return DBGSOM_OK;
     }
+    if (c->coll) {
+        const int rc = c->coll(c->coll_user, DBGSOM_COLL_ALLREDUCE, buf, count, (void *)c->stream);
+        if (rc != 0) {
+            (void)hipStreamSynchronize(c->stream);
+            set_error("collective callback failed (all-reduce, %d)", rc);
+            return DBGSOM_ECALLBACK;
+        }
+        return DBGSOM_OK;
+    }
     if (!c->allreduce) return DBGSOM_OK;
     const int rc = c->allreduce(c->allreduce_user, buf, count, (void *)c->stream);
     if (rc != 0) {
@@ -616,6 +645,42 @@ int run_allreduce(dbgsom_ctx *c, double *buf, int64_t count) {
         return DBGSOM_ECALLBACK;
     }
     return DBGSOM_OK;
+}
+
+// in place over nranks blocks of `per` values: op = DBGSOM_COLL_REDUCE_SCATTER leaves the SUM of block `rank` in
+// block `rank`; DBGSOM_COLL_ALLGATHER fills every block from its owner's
+int run_block_collective(dbgsom_ctx *c, int op, double *buf, int64_t per) {
+    if (c->rccl_comm) {
+        double *mine = buf + (size_t)c->coll_rank * per;
+        const int rc = op == DBGSOM_COLL_REDUCE_SCATTER
+                           ? g_rccl.reduce_scatter(buf, mine, (size_t)per, 8, 0, c->rccl_comm, c->stream)
+                           : g_rccl.all_gather(mine, buf, (size_t)per, 8, c->rccl_comm, c->stream);
+        if (rc != 0) {
+            (void)hipStreamSynchronize(c->stream);
+            set_error("%s failed (%d: %s)", op == DBGSOM_COLL_REDUCE_SCATTER ? "ncclReduceScatter" : "ncclAllGather", rc, rccl_err(rc));
+            return DBGSOM_ECALLBACK;
+        }
+        return DBGSOM_OK;
+    }
+    const int rc = c->coll ? c->coll(c->coll_user, op, buf, per, (void *)c->stream) : 1;
+    if (rc != 0) {
+        (void)hipStreamSynchronize(c->stream);
+        set_error("collective callback failed (op %d, %d)", op, rc);
+        return DBGSOM_ECALLBACK;
+    }
+    return DBGSOM_OK;
+}
+
+// does this epoch smooth column blocks?  (a function of the options, the collective and the shape alone:
+// every rank decides the same)
+bool shard_smoothing(const dbgsom_ctx *c, int64_t M, int64_t dp) {
+    if (c->shard_smooth == 0 || (c->coll_nranks < 2 && c->shard_smooth != 1)) return false;   // (one rank: only when forced -- tests)
+    const bool can = c->rccl_comm ? (g_rccl.reduce_scatter && g_rccl.all_gather) : c->coll != nullptr;
+    if (!can) return false;
+    // by default only where the replicated GEMM is worth two more launches and a second collective: from
+    // ~8 GFLOP (the C5 map: 68.7; the C4 map, 1.6 GFLOP in 48 us, is bound by its chain of k-tiles, not by the
+    // products, and would gain nothing)
+    return c->shard_smooth == 1 || 2.0 * (double)M * (double)M * (double)dp >= 8e9;
 }
 
 // What the next filtered search runs: an ARM = (seeds, digit planes).  Seeds: 0 = the cheap stateless
@@ -869,6 +934,23 @@ int accumulate_and_reduce(dbgsom_ctx *c, const int64_t *idx, const double *kw, d
         c->last_deferred = false;
     }
     c->sumsM = M;
+    c->sums_sharded = false;
+    if (shard_smoothing(c, M, s.dp)) {
+        // column blocks [S block | K | a | E | status] -> reduce-scatter: this rank's block holds the sums of all
+        // ranks for the columns it smooths, and the small vectors in full (copied behind the local S so that
+        // everything downstream finds K, a, E and the status flag where it always does)
+        const int G = c->coll_nranks;
+        const int64_t cb = smooth_block_cols(s.dp, G), blk = smooth_block_elems(M, s.dp, G);
+        TRY(c->shard_send.reserve((size_t)G * blk * 8));
+        double *send = c->shard_send.as<double>();
+        TRY(launch_pack_blocks(c->sums.as<double>(), M, s.dp, G, send, c->stream));
+        TRY(run_block_collective(c, DBGSOM_COLL_REDUCE_SCATTER, send, blk));
+        DBGSOM_HIP_CHECK(hipMemcpyAsync(c->sums.as<double>() + (size_t)M * s.dp, send + (size_t)c->coll_rank * blk + (size_t)M * cb,
+                                        (size_t)(3 * M + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+        c->sums_sharded = true;
+        c->sumsM = 0;   // (the S part of `sums` is this rank's share, not the reduced sums: nothing to read back)
+        return DBGSOM_OK;
+    }
     return run_allreduce(c, c->sums.as<double>(), count + 1);
 }
 
@@ -888,8 +970,23 @@ int smooth_and_fetch(dbgsom_ctx *c, int64_t M, double sigma, int layout, int fla
     TRY(c->sm_ws.reserve(smooth_workspace_bytes(M, dp)));
     double *chg = c->scal.as<double>();
     double *sums = c->sums.as<double>();
-    TRY(launch_smooth(sums, M, dp, c->hop.as<float>(), sigma, layout, c->Wb[c->cur].as<double>(),
-                      c->Wb[nxt].as<double>(), chg, c->sm_ws.p, c->sm_ws.cap, c->stream));
+    if (c->sums_sharded) {
+        const int G = c->coll_nranks, r = c->coll_rank;
+        const int64_t cb = smooth_block_cols(dp, G), blk = smooth_block_elems(M, dp, G);
+        const double *mine = c->shard_send.as<double>() + (size_t)r * blk;
+        TRY(c->shard_gather.reserve((size_t)G * M * cb * 8));
+        double *gather = c->shard_gather.as<double>();
+        TRY(launch_smooth_block(mine, mine + (size_t)M * cb, mine + (size_t)M * cb + M, M, cb, dp, c->hop.as<float>(), sigma,
+                                layout, gather + (size_t)r * M * cb, c->sm_ws.p, c->sm_ws.cap, c->stream));
+        TRY(run_block_collective(c, DBGSOM_COLL_ALLGATHER, gather, M * cb));
+        TRY(launch_rowchange_blocks(gather, M, dp, cb, c->Wb[c->cur].as<double>(), c->Wb[nxt].as<double>(), chg, c->sm_ws.p,
+                                    c->stream));
+        c->sums_sharded = false;
+        ++c->shard_epochs;
+    } else {
+        TRY(launch_smooth(sums, M, dp, c->hop.as<float>(), sigma, layout, c->Wb[c->cur].as<double>(),
+                          c->Wb[nxt].as<double>(), chg, c->sm_ws.p, c->sm_ws.cap, c->stream));
+    }
     mark(c, 3);
     // the epoch's small results: one kernel writes them into mapped page-locked memory, one stream
     // synchronisation
@@ -1015,7 +1112,8 @@ int dbgsom_ctx_create(int device, dbgsom_ctx **out) {
 #define CTX_DEVBUFS(c)                                                                                             \
     {&(c)->y, &(c)->hop, &(c)->hop_stage, &(c)->Wb[0], &(c)->Wb[1], &(c)->ww, &(c)->idx[0], &(c)->idx[1], &(c)->dist,  \
      &(c)->kw, &(c)->sums, &(c)->acc_ws, &(c)->sm_ws, &(c)->filt_ws, &(c)->scal, &(c)->qidx, &(c)->qdist, &(c)->red,  \
-     &(c)->hist, &(c)->stage_dev, &(c)->part_order, &(c)->part_ws, &(c)->part_counts, &(c)->shiftb}
+     &(c)->hist, &(c)->stage_dev, &(c)->part_order, &(c)->part_ws, &(c)->part_counts, &(c)->shiftb, &(c)->shard_send,    \
+     &(c)->shard_gather}
 
 int dbgsom_ctx_destroy(dbgsom_ctx *c) {
     if (!c) return DBGSOM_OK;
@@ -1053,6 +1151,9 @@ int dbgsom_ctx_set_option(dbgsom_ctx *c, const char *name, int64_t v) {
         c->use_graph = v != 0;
     } else if (!strcmp(name, "defer")) {
         c->defer = v != 0;
+    } else if (!strcmp(name, "shard_smooth")) {
+        DBGSOM_REQUIRE(v >= 0 && v <= 2, "shard_smooth must be 0 (never), 1 (whenever the collective can) or 2 (large maps)");
+        c->shard_smooth = (int)v;
     } else if (!strcmp(name, "refine")) {
         DBGSOM_REQUIRE(v >= 0 && v <= 2, "refine must be 0 (off), 1 (on) or 2 (by measurement)");
         c->refine = (int)v;
@@ -1081,6 +1182,10 @@ int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
     else if (!strcmp(name, "refine")) *v = c->refine;
     else if (!strcmp(name, "refined")) *v = c->last_refined ? 1 : 0;
     else if (!strcmp(name, "defer")) *v = c->defer;
+    else if (!strcmp(name, "shard_smooth")) *v = c->shard_smooth;
+    else if (!strcmp(name, "shard_epochs")) *v = c->shard_epochs;
+    else if (!strcmp(name, "collective_rank")) *v = c->coll_rank;
+    else if (!strcmp(name, "collective_ranks")) *v = c->coll_nranks;
     else if (!strcmp(name, "k2_filtered")) *v = c->last_k2_filtered ? 1 : 0;
     else if (!strcmp(name, "filter_min_query_rows")) *v = c->filter_min_query_rows;
     else if (!strcmp(name, "max_mean_candidates")) *v = c->max_mean_candidates;
@@ -1229,11 +1334,25 @@ int dbgsom_ctx_set_topology(dbgsom_ctx *c, const double *hop_host, int64_t M) {
     return DBGSOM_OK;
 }
 
+int dbgsom_ctx_set_collectives(dbgsom_ctx *c, dbgsom_collective_fn fn, void *user, int rank, int nranks) {
+    CTX_CHECK(c);
+    DBGSOM_REQUIRE(!fn || (nranks >= 1 && rank >= 0 && rank < nranks), "rank outside [0, nranks)");
+    drop_rccl(c);
+    c->allreduce = nullptr;
+    c->allreduce_user = nullptr;
+    c->coll = fn;
+    c->coll_user = user;
+    c->coll_rank = fn ? rank : 0;
+    c->coll_nranks = fn ? nranks : 1;
+    return DBGSOM_OK;
+}
+
 int dbgsom_ctx_set_allreduce(dbgsom_ctx *c, dbgsom_allreduce_fn fn, void *user) {
     CTX_CHECK(c);
     drop_rccl(c);
     c->allreduce = fn;
     c->allreduce_user = user;
+    c->coll = nullptr; c->coll_user = nullptr; c->coll_rank = 0; c->coll_nranks = 1;
     return DBGSOM_OK;
 }
 
@@ -1284,7 +1403,18 @@ int dbgsom_ctx_set_rccl(dbgsom_ctx *c, void *nccl_comm) {
     drop_rccl(c);
     c->rccl_comm = nccl_comm;
     c->rccl_owned = false;
-    if (nccl_comm) { c->allreduce = nullptr; c->allreduce_user = nullptr; }
+    c->coll_rank = 0; c->coll_nranks = 1;
+    if (nccl_comm) {
+        c->allreduce = nullptr; c->allreduce_user = nullptr;
+        c->coll = nullptr; c->coll_user = nullptr;
+        // rank and size of the communicator: what the sharded smoothing needs (absent symbols: it stays off)
+        int n = 1, r = 0;
+        if (g_rccl.comm_count && g_rccl.comm_user_rank && g_rccl.comm_count(nccl_comm, &n) == 0 &&
+            g_rccl.comm_user_rank(nccl_comm, &r) == 0 && n >= 1 && r >= 0 && r < n) {
+            c->coll_nranks = n;
+            c->coll_rank = r;
+        }
+    }
     return DBGSOM_OK;
 }
 

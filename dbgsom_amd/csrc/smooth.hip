@@ -393,6 +393,129 @@ __global__ __launch_bounds__(256) void rowchange_kernel(const double *__restrict
     if (t == 0) change_total[0] = tot[0];
 }
 
+// ---- smoothing sharded over the ranks of a sample-sharded job (columns of W') -------------------
+// W'[:, c] depends on column c of the centres and on nothing else of S, so rank r of G smooths the
+// columns [r cb, (r + 1) cb) only: the epoch's collective becomes a reduce-scatter of column blocks
+// [S[:, block] | K | a | E | status] (every rank then holds the reduced block it smooths and the small
+// vectors in full), the GEMM shrinks to M x M x cb per rank, and an all-gather of the W' blocks gives every
+// rank the same W' bit for bit.  The k range is cut as for the whole matrix (gemm_splits of the FULL
+// shape), so a column of W' is the same chain of the same pieces in either form.
+
+// [nblk][ S block (M x cb) | tail (tailn) ] from the row-major sums [S (M x d) | tail]; columns behind d: 0
+__global__ __launch_bounds__(256) void pack_blocks_kernel(const double *__restrict__ sums, int M, int d, int cb,
+                                                          int nblk, int64_t blk, int tail_count,
+                                                          double *__restrict__ out) {
+    const int i = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    double *dst = out + (size_t)b * blk;
+    if (i < M) {
+        for (int cc = t; cc < cb; cc += 256) {
+            const int c = b * cb + cc;
+            dst[(size_t)i * cb + cc] = c < d ? sums[(size_t)i * d + c] : 0.0;
+        }
+    } else {   // (workgroups M ..: the tail, 256 values each)
+        const int e = (i - M) * 256 + t;
+        const int64_t tailn = blk - (int64_t)M * cb;
+        if (e < tailn) dst[(size_t)M * cb + e] = e < tail_count ? sums[(size_t)M * d + e] : 0.0;
+    }
+}
+
+// W'_block[i, c] = (sum of the split-K pieces in piece order) / den[i]
+__global__ __launch_bounds__(256) void combine_block_kernel(const double *__restrict__ part, const double *__restrict__ den,
+                                                            int M, int cb, int splits, double *__restrict__ Wb) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)M * cb) return;
+    double p = part[e];
+    for (int z = 1; z < splits; ++z) p += part[(size_t)z * M * cb + e];
+    Wb[e] = p / den[e / cb];
+}
+
+// the gathered blocks [nblk][M][cb] -> W' row-major (M x d), and the row changes as rowchange_kernel forms them
+__global__ __launch_bounds__(256) void rowchange_blocks_kernel(const double *__restrict__ Wo, double *__restrict__ Wn,
+                                                               int M, int d, int cb,
+                                                               const double *__restrict__ blocks,
+                                                               double *__restrict__ rowchg,
+                                                               uint32_t *__restrict__ ticket,
+                                                               double *__restrict__ change_total) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int i = blockIdx.x * RC_ROWS + (t >> 6);
+    if (i < M) {
+        double s = 0.0;
+        for (int c = lane; c < d; c += 64) {
+            const int b = c / cb;
+            const double wn = blocks[((size_t)b * M + i) * cb + (c - b * cb)];
+            Wn[(size_t)i * d + c] = wn;
+            const double df = Wo[(size_t)i * d + c] - wn;
+            s += df * df;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) rowchg[i] = sqrt(s);
+    }
+    if (!last_workgroup_done(ticket, gridDim.x)) return;
+    __shared__ double tot[256];
+    double p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        double v = 0.0;
+        for (int j = t + 256 * u; j < M; j += 1024) v += rowchg[j];
+        p[u] = v;
+    }
+    tot[t] = (p[0] + p[2]) + (p[1] + p[3]);
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) tot[t] += tot[t + w];
+        __syncthreads();
+    }
+    if (t == 0) change_total[0] = tot[0];
+}
+
+int64_t smooth_block_cols(int64_t d, int nranks) {
+    const int64_t cb = (d + nranks - 1) / nranks;
+    return (cb + 1) / 2 * 2;   // (16-byte rows for the GEMM's LDS-DMA)
+}
+int64_t smooth_block_elems(int64_t M, int64_t d, int nranks) {
+    return M * smooth_block_cols(d, nranks) + (3 * M + 1 + 1) / 2 * 2;
+}
+
+int launch_pack_blocks(const double *sums, int64_t M, int64_t d, int nranks, double *out, hipStream_t s) {
+    const int64_t cb = smooth_block_cols(d, nranks), blk = smooth_block_elems(M, d, nranks);
+    const int64_t tailn = blk - M * cb;
+    hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)(M + (tailn + 255) / 256), (unsigned)nranks), dim3(256), 0, s, sums,
+                       (int)M, (int)d, (int)cb, nranks, blk, (int)(3 * M + 1), out);
+    return launch_status("pack_blocks_kernel");
+}
+
+// this rank's block of W' (M x cb, into Wb) from its reduced block of the sums
+int launch_smooth_block(const double *S_b, const double *K, const double *a, int64_t M, int64_t cb, int64_t d_full,
+                        const float *hop, double sigma, int layout, double *Wb, void *ws, size_t ws_bytes,
+                        hipStream_t s) {
+    DBGSOM_REQUIRE(M >= 1 && M <= 0x7fff && cb >= 2 && cb % 2 == 0 && cb <= d_full + 1 && d_full <= 0x7ffffff0, "bad shape");
+    DBGSOM_REQUIRE(S_b && K && a && hop && Wb && ws && sigma > 0.0, "bad arguments");
+    if (ws_bytes < smooth_workspace_bytes(M, d_full)) { set_error("dbgsom_smooth: workspace too small"); return DBGSOM_ENOMEM; }
+    SmoothWs w;
+    carve_smooth(&w, (char *)ws, M, d_full);
+    const int Mi = (int)M, ci = (int)cb, Mp = (int)smooth_mp(M);
+    hipLaunchKernelGGL(smooth_prep_kernel, dim3((unsigned)M), dim3(256), 0, s, S_b, K, a, hop, Mi, ci, layout,
+                       2.0 * (sigma * sigma), w.C, w.G, w.den, w.ticket, Mp);
+    const int splits = gemm_splits(M, d_full);   // (the pieces of the whole matrix: the same bits in either form)
+    hipLaunchKernelGGL(smooth_gemm_kernel, dim3((unsigned)((cb + GT - 1) / GT), (unsigned)((M + GR - 1) / GR), (unsigned)splits),
+                       dim3(256), 0, s, w.G, w.C, w.den, Mi, Mp, ci, splits, w.part, Wb);
+    if (splits > 1)
+        hipLaunchKernelGGL(combine_block_kernel, dim3((unsigned)((M * cb + 255) / 256)), dim3(256), 0, s, w.part, w.den, Mi, ci,
+                           splits, Wb);
+    return launch_status("smooth block kernels");
+}
+
+// W' (row-major) and the convergence norm from the gathered blocks
+int launch_rowchange_blocks(const double *blocks, int64_t M, int64_t d, int64_t cb, const double *W_old, double *W_new,
+                            double *change_total, void *ws, hipStream_t s) {
+    SmoothWs w;
+    carve_smooth(&w, (char *)ws, M, d);
+    hipLaunchKernelGGL(rowchange_blocks_kernel, dim3((unsigned)((M + RC_ROWS - 1) / RC_ROWS)), dim3(256), 0, s, W_old, W_new,
+                       (int)M, (int)d, (int)cb, blocks, w.rowchg, w.ticket, change_total);
+    return launch_status("rowchange_blocks_kernel");
+}
+
 int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, double sigma,
                   int layout, const double *W_old, double *W_new, double *change_total, void *ws,
                   size_t ws_bytes, hipStream_t s) {

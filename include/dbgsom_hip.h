@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DBGSOM_ABI_VERSION 3
+#define DBGSOM_ABI_VERSION 4
 
 /* sample storage types (the reference accepts float64 and float32 input: SomVQ.py:121-124) */
 #define DBGSOM_F32 0
@@ -317,6 +317,23 @@ int dbgsom_rccl_unique_id(char *id128);
 int dbgsom_rccl_comm_init(const char *id128, int nranks, int rank, void **comm_out);
 int dbgsom_rccl_comm_destroy(void *comm);
 int dbgsom_ctx_set_rccl(dbgsom_ctx *ctx, void *nccl_comm);
+/* The callback seam with everything the epoch can use: one function, three operations on float64 values in
+ * HBM, ordered on `stream`, all in place.
+ *   DBGSOM_COLL_ALLREDUCE       buf[0 .. count): element-wise SUM over the ranks (as dbgsom_allreduce_fn)
+ *   DBGSOM_COLL_REDUCE_SCATTER  buf holds nranks blocks of `count` values; on return block `rank` holds the SUM
+ *                               of that block over the ranks (ncclReduceScatter(buf, buf + rank * count, count))
+ *   DBGSOM_COLL_ALLGATHER       block `rank` of nranks blocks of `count` values is this rank's; on return every
+ *                               block holds its owner's (ncclAllGather(buf + rank * count, buf, count))
+ * With the last two (or with RCCL, dbgsom_ctx_set_rccl) the epoch can shard the neighbourhood smoothing
+ * (BaseSom.py:509-515) over the ranks: column c of the new prototypes needs column c of the Voronoi sums and
+ * nothing else of them, so the sums are reduce-scattered as column blocks [S block | K | a | E | status], each
+ * rank smooths its d / nranks columns, and an all-gather of the blocks leaves the same W' on every rank bit for
+ * bit -- the same bytes on the wire as the all-reduce, 1 / nranks of the M x M x d product per rank.  Option
+ * "shard_smooth": 0 never, 1 whenever the collective can, 2 (default) from ~8 GFLOP of smoothing (2 M^2 d).
+ * Results equal the replicated form's bit for bit whenever the reduced sums do (two ranks: always). */
+enum { DBGSOM_COLL_ALLREDUCE = 0, DBGSOM_COLL_REDUCE_SCATTER = 1, DBGSOM_COLL_ALLGATHER = 2 };
+typedef int (*dbgsom_collective_fn)(void *user, int op, double *buf_dev, int64_t count, void *stream);
+int dbgsom_ctx_set_collectives(dbgsom_ctx *ctx, dbgsom_collective_fn fn, void *user, int rank, int nranks);
 /* element-wise SUM of `n` host float64 values over the ranks of the context's collective (RCCL or
  * callback; identity for a single rank): what a caller without a communication library of its own needs
  * around the epochs (moments of the data, the start prototypes from rank 0, a barrier, timings) */

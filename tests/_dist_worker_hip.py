@@ -47,6 +47,17 @@ def main():
         res[f"{tag}_hits"], res[f"{tag}_dens"] = hits, dens
         res[f"{tag}_filtered"] = bool(be.filter_log and be.filter_log[-1][0] == "filtered")
         res[f"{tag}_planes"] = int(be.filter_log[-1][2]) if res[f"{tag}_filtered"] else -1
+        # the same epoch with the smoothing sharded over the ranks (reduce-scatter of column blocks of the sums,
+        # every rank smooths d / world columns, all-gather of the new prototypes)
+        be.shard_smooth = 1
+        n0 = be.shard_epochs
+        rs = be.epoch(W, hop, 1.1, 0.002, "compact", True, n_classes=4)
+        res[f"{tag}_shard_ran"] = be.shard_epochs - n0
+        res[f"{tag}_shard_new_weights"], res[f"{tag}_shard_change_total"] = rs.new_weights, rs.change_total
+        res[f"{tag}_shard_errors"], res[f"{tag}_shard_activations"] = rs.errors, rs.activations
+        res[f"{tag}_shard_winners"] = rs.winners
+        if tag == "filt":   # (two legs in the default form, one with the sharded smoothing still on)
+            be.shard_smooth = 2
         # a winner out of range on ONE rank must fail on EVERY rank (status rides in the reduced buffer)
         bad = r.winners.copy()
         if rank == 0:

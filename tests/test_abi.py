@@ -26,7 +26,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in _native.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_native.SIGNATURES) == set(names)
-    assert lib.dbgsom_abi_version() == _native.ABI_VERSION == 3
+    assert lib.dbgsom_abi_version() == _native.ABI_VERSION == 4
 
 
 def test_argument_errors_are_status_codes_not_exceptions():

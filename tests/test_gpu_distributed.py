@@ -77,6 +77,19 @@ def test_hip_backend_two_ranks_one_gpu(world, tmp_path):
             assert np.array_equal(r[f"{tag}_hits"], hits1)
             np.testing.assert_allclose(r[f"{tag}_dens"], dens1, rtol=1e-12, atol=1e-300)
             assert bool(r[f"{tag}_range_error"])        # every rank raised, none hung
+            # smoothing sharded over the ranks: the same prototypes on every rank bit for bit; against the
+            # replicated form bit for bit when the reduced sums are (two ranks: a + b in either collective)
+            assert int(r[f"{tag}_shard_ran"]) == 1
+            assert np.array_equal(r[f"{tag}_shard_new_weights"], res[0][f"{tag}_shard_new_weights"])
+            assert np.array_equal(r[f"{tag}_shard_winners"], r[f"{tag}_winners"])
+            assert np.array_equal(r[f"{tag}_shard_activations"], r1.activations)
+            if world == 2:
+                assert np.array_equal(r[f"{tag}_shard_new_weights"], r[f"{tag}_new_weights"])
+                assert float(r[f"{tag}_shard_change_total"]) == float(r[f"{tag}_change_total"])
+                assert np.array_equal(r[f"{tag}_shard_errors"], r[f"{tag}_errors"])
+            np.testing.assert_allclose(r[f"{tag}_shard_new_weights"], r1.new_weights, rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(r[f"{tag}_shard_errors"], r1.errors, rtol=1e-12)
+            np.testing.assert_allclose(r[f"{tag}_shard_change_total"], r1.change_total, rtol=1e-10)
         one.release()
     # whole fits: replicated X == the reference's golden fit; per-rank shards == the same map
     name = "lowd_linear"
@@ -105,3 +118,70 @@ def test_hip_backend_two_ranks_one_gpu(world, tmp_path):
         assert int(r["clf_n_iter"]) == clf.n_iter_
         assert [tuple(n) for n in r["clf_neurons"]] == clf.neurons_
         np.testing.assert_allclose(r["clf_weights"], clf.weights_, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("G,d,rows,cols", [(2, 72, 13, 14), (3, 72, 13, 14), (8, 72, 13, 14), (8, 40, 5, 6), (12, 16, 5, 6),
+                                           (8, 130, 20, 21)])
+@pytest.mark.parametrize("layout", ["compact", "aligned"])
+def test_sharded_smoothing_blocks_equal_the_replicated_form(G, d, rows, cols, layout):
+    """Every rank's part of the sharded smoothing on ONE GPU: G virtual ranks, one after the other, through
+    the callback seam (dbgsom_ctx_set_collectives).  With one real rank the reduce-scatter is the identity, so
+    each virtual rank's block of W' comes from the full sums; a first pass collects the blocks, a second one
+    hands every rank all of them at its all-gather.  The epoch's results must then equal the replicated
+    smoothing's bit for bit -- for block widths that do not divide d, blocks beyond the last column, both
+    layouts of the centres with dead neurons, maps with and without a split k range."""
+    import torch
+
+    from dbgsom_amd import _native
+    from dbgsom_amd.backend import HipBackend, _DeviceArray
+
+    N = 5000
+    M = rows * cols
+    X, _ = gi.blobs_f32(N, d, 33)
+    rng = np.random.default_rng(5)
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    W[::7] += 1e3          # dead neurons: rows nobody wins (quirk Q1 moves the centres in the compact layout)
+    hop = gi.lattice_hops(rows, cols)
+    one = HipBackend(0).load(X)
+    ref = one.epoch(W, hop, 1.3, 0.004, layout, True)
+    assert (ref.activations == 0).sum() >= M // 8
+    one.release()
+    dev = torch.device("cuda", 0)
+    saved, ops = {}, []
+    for pass_ in (0, 1):
+        for r in range(G):
+            be = HipBackend(0).load(X)
+
+            def coll(_user, op, ptr, count, stream, r=r, pass_=pass_):
+                try:
+                    ops.append(op)
+                    if op != _native.COLL_ALLGATHER:
+                        return 0           # one real rank: sums and reduce-scattered blocks are already the totals
+                    ext = torch.cuda.ExternalStream(stream, device=dev)
+                    with torch.cuda.stream(ext):
+                        t = torch.as_tensor(_DeviceArray(ptr, count * G), device=dev)
+                        if pass_ == 0:
+                            saved[r] = t[r * count:(r + 1) * count].clone()
+                            t[:r * count].fill_(float("nan"))
+                            t[(r + 1) * count:].fill_(float("nan"))
+                        else:
+                            for q in range(G):
+                                if q != r:
+                                    t[q * count:(q + 1) * count].copy_(saved[q])
+                        ext.synchronize()
+                    return 0
+                except BaseException:  # noqa: BLE001
+                    return 1
+
+            cb = _native.COLLECTIVE_FN(coll)
+            _native.call("dbgsom_ctx_set_collectives", be._ctx, cb, None, r, G)
+            be.shard_smooth = 1
+            res = be.epoch(W, hop, 1.3, 0.004, layout, True)
+            assert be.shard_epochs == 1
+            assert np.array_equal(res.winners, ref.winners) and np.array_equal(res.activations, ref.activations)
+            assert np.array_equal(res.errors, ref.errors)
+            if pass_ == 1:
+                assert np.array_equal(res.new_weights, ref.new_weights, equal_nan=True)
+                assert res.change_total == ref.change_total
+            be.release()
+    assert ops.count(_native.COLL_REDUCE_SCATTER) == 2 * G and ops.count(_native.COLL_ALLGATHER) == 2 * G

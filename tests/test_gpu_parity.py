@@ -366,6 +366,15 @@ def epoch():
     np.testing.assert_allclose(Wn, oo.new_weights, rtol=1e-11, atol=1e-13)
     return Wn
 W_lib = epoch()                                               # RCCL issued by the library
+# ... and the smoothing in its sharded form on the same communicator: ncclReduceScatter of the (one) column block
+# of the sums and ncclAllGather of the new prototypes, in place, issued by the library (forced: it is off for
+# one rank and for maps this small)
+nat.call("dbgsom_ctx_set_option", ctx, b"shard_smooth", 1)
+W_shard = epoch()
+n_shard = ctypes.c_int64(0)
+nat.call("dbgsom_ctx_get_option", ctx, b"shard_epochs", ctypes.byref(n_shard))
+assert n_shard.value == 1 and np.array_equal(W_shard, W_lib)
+nat.call("dbgsom_ctx_set_option", ctx, b"shard_smooth", 2)
 rccl = ctypes.CDLL(os.environ["DBGSOM_RCCL_LIB"])             # (the librccl of the HIP runtime in use)
 rccl.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                ctypes.c_void_p, ctypes.c_void_p]
