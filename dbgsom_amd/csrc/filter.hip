@@ -2058,7 +2058,10 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
 // takes the workgroups whose list length falls in its class (<= 16, 17..32, > 32) so that the
 // gathered X tile is streamed once for all but the longest lists (a fourth class of 64 was
 // measured: no gain at C3 / C4, slower at C2).
-template <typename XT, int JTL, int NWV, int SPLIT = 1, int K = 1>
+// NS = stages of the ring (NS - 1 tiles in flight).  3 where the chip is full of workgroups; the 64-sample
+// workgroups of a small sample set (one or two rounds of workgroups) take as many stages as fit four
+// workgroups per CU: 6 / 5 / 4 for JTL = 1 / 2 / 3 (C2 stage 99 -> 91 us, a 125 k-row share of C4 235 -> 212).
+template <typename XT, int JTL, int NWV, int SPLIT = 1, int K = 1, int NS = 3>
 __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
     const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
     const double *__restrict__ W, int M, const double *__restrict__ ww,
@@ -2077,11 +2080,8 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
     // X tile: 128 rows x KT values, float32 (64-byte rows) or float64 (128-byte rows, laid out like W)
     constexpr int XROW = KT * (int)sizeof(XT), XCH = XROW / 16, XD = RW * XROW / 1024 / NWV;
     constexpr int S_XT = RW * XROW, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 / 16 KB (SPLIT: half) + 2 JTL KB
-#if SUBSET_EXPERIMENT & 64
-    __shared__ __attribute__((aligned(16))) char smem[6 * S_STAGE];  // halves the blocks per CU
-#else
-    __shared__ __attribute__((aligned(16))) char smem[3 * S_STAGE];
-#endif
+    static_assert(NS >= 3 && NS <= 8, "3 .. 8 stages");
+    __shared__ __attribute__((aligned(16))) char smem[NS * S_STAGE];
 #if SUBSET_EXPERIMENT & 32
     return;
 #endif
@@ -2173,7 +2173,7 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             if (u < n_wdma) fdma16(wrow[u] + k0, stage + S_XT + 1024 * (wq0 + u));
-        i_stage = (i_stage == 2 * S_STAGE) ? 0 : i_stage + S_STAGE;
+        i_stage = (i_stage == (NS - 1) * S_STAGE) ? 0 : i_stage + S_STAGE;
         if (++i_kt == nkt) { i_kt = 0; ++i_step; }
     };
 
@@ -2202,8 +2202,9 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
 #pragma unroll
         for (int it = 0; it < IT; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
 
-    if (ntile > 0) issue();
-    if (ntile > 1) issue();
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (ntile > u) issue();
     int kt = 0, st = 0, r_stage = 0;
 #if SUBSET_EXPERIMENT & 128
     t_loop = __builtin_amdgcn_s_memtime();
@@ -2215,13 +2216,23 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
 #endif
     for (int t = 0; t < ntile; ++t) {
         STAMP(0);
-        // each wavefront waits for ITS OWN DMAs of tile t, the barrier then covers everybody's
-        if (t + 1 < ntile) {
-            if (n_wdma == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XD + 2) : "memory");
-            else if (n_wdma == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XD + 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XD) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // each wavefront waits for ITS OWN DMAs of tile t, the barrier then covers everybody's: what may stay
+        // in flight are the tiles issued behind it -- NS - 2 of them, fewer at the end of the walk
+        {
+            const int behind = ntile - 1 - t;
+#define DBGSOM_WAIT_BEHIND(Q)                                                                        \
+            if (n_wdma == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Q) * (XD + 2)) : "memory");      \
+            else if (n_wdma == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Q) * (XD + 1)) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Q) * XD) : "memory")
+            static_assert((NS - 2) * (XD + 2) <= 63, "vmcnt is a 6-bit counter");
+            if (behind >= NS - 2) { DBGSOM_WAIT_BEHIND(NS - 2); }
+            else if (NS > 3 && behind == 1) { DBGSOM_WAIT_BEHIND(1); }
+            else if (NS > 4 && behind == 2) { DBGSOM_WAIT_BEHIND(NS > 4 ? 2 : 0); }
+            else if (NS > 5 && behind == 3) { DBGSOM_WAIT_BEHIND(NS > 5 ? 3 : 0); }
+            else if (NS > 6 && behind == 4) { DBGSOM_WAIT_BEHIND(NS > 6 ? 4 : 0); }
+            else if (NS > 7 && behind == 5) { DBGSOM_WAIT_BEHIND(NS > 7 ? 5 : 0); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef DBGSOM_WAIT_BEHIND
         }
         STAMP(1);
 #if !(SUBSET_EXPERIMENT & 16)
@@ -2229,10 +2240,10 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
 #endif
         STAMP(2);
         asm volatile("" ::: "memory");
-        if (t + 2 < ntile) issue();
+        if (t + (NS - 1) < ntile) issue();
         STAMP(3);
         const char *stage = smem + r_stage;
-        r_stage = (r_stage == 2 * S_STAGE) ? 0 : r_stage + S_STAGE;
+        r_stage = (r_stage == (NS - 1) * S_STAGE) ? 0 : r_stage + S_STAGE;
 #pragma unroll
         for (int ks = 0; ks < KT / 4; ++ks) {
             double a[JTL], b[IT];
@@ -2894,14 +2905,16 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
                                xx_dev, W_dev, ww_dev, f.ulist, (int)f.Mpad, f.ucount, f.ovf, f.rf_qlen + 2, f.ovf_cand, round_f32,
                                idx_dev, dist_dev);
     }
+    // (stages of the 64-sample workgroups' ring: what fits four workgroups per CU, 40 KB each)
+#define SPLIT_NS(JTL, XS) ((40 * 1024) / (64 * 16 * (XS) + (JTL) * 16 * 16 * 8) > 6 ? 6 : ((40 * 1024) / (64 * 16 * (XS) + (JTL) * 16 * 16 * 8) < 3 ? 3 : (40 * 1024) / (64 * 16 * (XS) + (JTL) * 16 * 16 * 8)))
 #define DBGSOM_SUBSET_W(JTL, NWV_, STREAM)                                                        \
     do {                                                                                          \
         if (exact_split && x_dtype == DBGSOM_F32)                                                 \
-            hipLaunchKernelGGL((subset_exact_kernel<float, JTL, 4, 2>), dim3((unsigned)(2 * f.nb)), dim3(256), 0, STREAM, \
+            hipLaunchKernelGGL((subset_exact_kernel<float, JTL, 4, 2, 1, SPLIT_NS(JTL, 4)>), dim3((unsigned)(2 * f.nb)), dim3(256), 0, STREAM, \
                                (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
                                order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
         else if (exact_split)                                                                     \
-            hipLaunchKernelGGL((subset_exact_kernel<double, JTL, 4, 2>), dim3((unsigned)(2 * f.nb)), dim3(256), 0, STREAM, \
+            hipLaunchKernelGGL((subset_exact_kernel<double, JTL, 4, 2, 1, SPLIT_NS(JTL, 8)>), dim3((unsigned)(2 * f.nb)), dim3(256), 0, STREAM, \
                                (const double *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
                                order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
         else if (x_dtype == DBGSOM_F32)                                                           \
@@ -2959,6 +2972,7 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
     }
 #undef DBGSOM_SUBSET
 #undef DBGSOM_SUBSET_W
+#undef SPLIT_NS
 #undef DBGSOM_SWEEP
 #undef S4_LAUNCH
     if (fork) {
