@@ -147,7 +147,13 @@ struct FilteredCall {
     const void *X_store = nullptr;
     int store_dtype = -1;
     int64_t ld_store = 0;
+    // > 0: the call waits for its candidate lists and, when they average more than this, returns
+    // DBGSOM_LISTS_LONG without the exact stage (idx / dist untouched): an arm of the search policy that has
+    // never run on this map may leave the whole map a candidate, and the exact stage over such lists costs
+    // twice the all-pairs search the caller can run instead
+    double guard_mean = 0.0;
 };
+constexpr int DBGSOM_LISTS_LONG = 1000;   // (internal status of launch_bmu_filtered, never crosses the ABI)
 int launch_bmu_filtered(const FilteredCall &call);
 size_t smooth_workspace_bytes(int64_t M, int64_t d);
 int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, double sigma,

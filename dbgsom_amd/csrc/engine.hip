@@ -288,6 +288,9 @@ struct dbgsom_ctx {
     int planes_next = 1, planes_used = 1;   // 1 .. 3 digit planes of the sweep; 0 = no sweep (triangle pruning)
     bool probe_next = false, last_probed = false;  // a counting-only pruning launch beside the sweep
     bool last_retry = false;
+    bool exploring_next = false;   // the next epoch runs an arm that has never run on this map (adapt_arms)
+    bool last_guarded = false;     // the last filtered search stopped at its lists and ran all pairs instead
+    int64_t guarded_calls = 0;
     bool prune_retry = false;  // the last pruning launch met workgroups with poor seeds: re-seed those (DBGSOM_PRUNE_RETRY)
     // `dist` holds the exact distances of the resident samples to the rows idx[icur] of Wb[distW_buf]
     // (distW_M rows) as the last epoch's search left them: the hinted pruning bound (filter.hip 2c)
@@ -526,6 +529,7 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     c->rf_measuring = -1;
     c->rf_arm = 4 * (prev_idx ? 2 : (c->last_seed_full ? 1 : 0)) + c->planes_used;
     if (c->refine == 2 && mean_known) {
+        if (c->rf_M > 0 && llabs((long long)(M - c->rf_M)) * 4 <= (long long)c->rf_M) c->rf_M = M;   // (a growth step: see adapt_arms)
         if (c->rf_M != M) {
             c->rf_M = M;
             for (auto &r : c->rf) r = dbgsom_ctx::RefineTimes();
@@ -555,8 +559,26 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     c->last_deferred = call.defer_dist;
     c->last_round_f32 = round_f32;
     if (s.dtype == DBGSOM_BF16) { call.X_store = s.X; call.store_dtype = DBGSOM_BF16; call.ld_store = s.dp; }
-    TRY(launch_bmu_filtered(call));
+    // An arm on trial (`auto`, a training epoch, nothing known of this arm on this map): the call stops at lists
+    // that average more than the policy bears and the all-pairs kernel finds the winners instead -- the policy
+    // still learns what the arm leaves, for the price of its sweep instead of an exact stage over the whole map.
+    c->last_guarded = false;
+    const int arm_row = prev_idx ? 2 : (c->last_seed_full ? 1 : 0);
+    if (may_probe && c->algorithm == DBGSOM_ALG_AUTO && call.k == 1 &&
+        (c->planeM != M || isnan(c->arm_seen[arm_row][c->planes_used])))
+        call.guard_mean = (double)c->max_mean_candidates;
+    const int rc_f = launch_bmu_filtered(call);
     c->last_filter_M = M; c->last_filter_N = s.N; c->last_filter_d = s.dp; c->last_filter_ws = ws.p;
+    if (rc_f == DBGSOM_LISTS_LONG) {
+        c->last_guarded = true;
+        ++c->guarded_calls;
+        c->last_refined = false;
+        c->last_deferred = false;
+        c->rf_measuring = -1;
+        return launch_bmu(s.Xb, s.bdtype, s.N, s.dp, s.dp, s.xx.as<double>(), W, M, c->ww.as<double>(), 1, round_f32, idx,
+                          dist, c->stream);
+    }
+    TRY(rc_f);
     return DBGSOM_OK;
 }
 
@@ -697,8 +719,14 @@ bool shard_smoothing(const dbgsom_ctx *c, int64_t M, int64_t dp) {
 // When nothing is left to try it stays for PLANES_REPROBE epochs, then forgets the alternatives.
 // Results never depend on any of this.
 void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
+    c->exploring_next = false;
     const int row = c->last_hinted ? 2 : (c->last_seed_full ? 1 : 0);
     const int p = c->planes_used;
+    // A growing map changes its size by a few neurons at a time: what the arms left on a map within a quarter of
+    // this one's size stays the best guess there is (lists and times move with it by a few per cent, and every arm
+    // is looked at again as it ages) -- forgetting it at every growth step made every step pay for the
+    // exploration again, on unclustered data an epoch or two at ten times the settled cost.
+    if (c->planeM > 0 && c->planeM != M && llabs((long long)(M - c->planeM)) * 4 <= (long long)c->planeM) c->planeM = M;
     if (c->planeM != M) {  // another map size: what was learnt no longer applies
         c->planeM = M;
         for (auto &r : c->arm_known) for (double &k : r) k = NAN;
@@ -755,6 +783,7 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
                 c->seed_mode = ds == 1 ? 1 : 0;
                 c->planes_next = dq;
                 c->plane_hold = 0;
+                c->exploring_next = true;
                 return;
             }
         }
@@ -828,6 +857,7 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
     if (es >= 0) {
         c->seed_mode = es == 1 ? 1 : 0;
         c->planes_next = ep;
+        c->exploring_next = true;
     } else {
         c->seed_mode = bs == 1 ? 1 : 0;
         c->planes_next = bp;
@@ -863,9 +893,14 @@ void update_policy(dbgsom_ctx *c, double list_sum, double probe_sum, double retr
     if (again) c->probe_next = true;
     if (c->algorithm == DBGSOM_ALG_AUTO) {
         // (the cheapest arm known so far, not an arm that is only being looked at)
-        if (c->best_mean > (double)c->max_mean_candidates) {  // exponential back-off, capped
+        // (not while an arm that has never run on this map is up next: on unclustered data the strong corner --
+        //  good seeds and a finer sweep -- is what works, and eight all-pairs epochs in front of its first try
+        //  cost forty settled ones)
+        if (c->best_mean > (double)c->max_mean_candidates && !c->exploring_next) {  // exponential back-off, capped
             c->filter_fail = c->filter_fail < 6 ? c->filter_fail + 1 : 6;
             c->filter_backoff = FILTER_BACKOFF << (c->filter_fail - 1);
+        } else if (c->best_mean > (double)c->max_mean_candidates) {
+            // (exploring)
         } else {
             c->filter_fail = 0;
         }
@@ -1184,6 +1219,7 @@ int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
     else if (!strcmp(name, "defer")) *v = c->defer;
     else if (!strcmp(name, "shard_smooth")) *v = c->shard_smooth;
     else if (!strcmp(name, "shard_epochs")) *v = c->shard_epochs;
+    else if (!strcmp(name, "guarded_calls")) *v = c->guarded_calls;
     else if (!strcmp(name, "collective_rank")) *v = c->coll_rank;
     else if (!strcmp(name, "collective_ranks")) *v = c->coll_nranks;
     else if (!strcmp(name, "k2_filtered")) *v = c->last_k2_filtered ? 1 : 0;
@@ -1595,7 +1631,7 @@ int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f
             ++r.n[measuring];
         }
         c->last_frozen = (flags & DBGSOM_EPOCH_FROZEN) != 0;
-        c->last_epoch_ms = (c->last_filtered && !c->last_probed && measuring < 0 && !W_new_host && !idx_host && !dist_host)
+        c->last_epoch_ms = (c->last_filtered && !c->last_probed && !c->last_guarded && measuring < 0 && !W_new_host && !idx_host && !dist_host)
                                ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()
                                : NAN;
         update_policy(c, c->tail.as<double>()[2 * M + 2], c->tail.as<double>()[2 * M + 3], c->tail.as<double>()[2 * M + 4],

@@ -2818,6 +2818,16 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
                            f.yypad, f.ctab, f.summary, (int)M, prev_idx_dev, order_dev, f.ulist, (int)f.Mpad, f.ucount,
                            (int64_t *)nullptr, 1, (int)f.Mpad, 0, (const int32_t *)nullptr, f.sched_ctr);
     g_timer.mark(4, s);
+    if (call.guard_mean > 0.0) {   // (an arm on trial: see FilteredCall::guard_mean)
+        unsigned long long sum_h = 0;
+        DBGSOM_HIP_CHECK(hipMemcpyAsync(&sum_h, f.sched_ctr + SCHED_SUM, 8, hipMemcpyDeviceToHost, s));
+        DBGSOM_HIP_CHECK(hipStreamSynchronize(s));
+        if ((double)sum_h > call.guard_mean * (double)f.nb) {
+            g_timer.mark(5, s);
+            g_timer.valid = g_timer.enabled;
+            return DBGSOM_LISTS_LONG;
+        }
+    }
     // per-sample refinement of the lists (section 2d): workgroups it takes leave the MFMA stage's schedule
     const int rf_rows = call.refine_rows;
     const bool refine = rf_rows > 0;
