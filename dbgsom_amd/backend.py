@@ -331,21 +331,43 @@ class HipBackend(HotPathBackend):
             # RCCL driven by the library itself (dbgsom_ctx_set_rccl): no callback, no interpreter in the
             # epoch.  One communicator per process and device, made once (torch.distributed only carries
             # rank 0's 128-byte id to the other ranks) and shared by every context of this process.
-            comm = _RCCL_COMMS.get(self.device_index)
-            if comm is None:
-                uid = ctypes.create_string_buffer(128)
+            comm = _RCCL_COMMS.get(self.device_index, "untried")
+            if comm == "untried":
+                # (every rank goes through every step and the ranks then agree on the outcome: a communicator
+                #  that came up on some ranks only must not be used by any)
+                uid, err = ctypes.create_string_buffer(128), None
                 if rank == 0:
-                    _native.call("dbgsom_rccl_unique_id", uid)
-                box = [uid.raw]
+                    try:
+                        _native.call("dbgsom_rccl_unique_id", uid)
+                    except Exception as e:  # noqa: BLE001
+                        err = e
+                box = [uid.raw if err is None else None]
                 td.broadcast_object_list(box, src=0)
-                uid = ctypes.create_string_buffer(box[0], 128)
-                self._get("n_samples")   # (a context call: this thread is on the context's device)
                 comm = ctypes.c_void_p()
-                _native.call("dbgsom_rccl_comm_init", uid, world, rank, ctypes.byref(comm))
-                _RCCL_COMMS[self.device_index] = comm
-            _native.call("dbgsom_ctx_set_rccl", self._ctx, comm)
-            self._cb = None
-            return
+                if box[0] is not None:
+                    try:
+                        uid = ctypes.create_string_buffer(box[0], 128)
+                        self._get("n_samples")   # (a context call: this thread is on the context's device)
+                        _native.call("dbgsom_rccl_comm_init", uid, world, rank, ctypes.byref(comm))
+                    except Exception as e:  # noqa: BLE001
+                        err, comm = e, ctypes.c_void_p()
+                else:
+                    err = err or RuntimeError("rank 0 could not make an RCCL id")
+                ok = torch.tensor([1 if (err is None and comm.value) else 0], device=dev, dtype=torch.int32)
+                td.all_reduce(ok, op=td.ReduceOp.MIN)
+                if int(ok.item()) == 1:
+                    _RCCL_COMMS[self.device_index] = comm
+                else:
+                    # the library could not drive RCCL itself in this process (its librccl is not the one of the
+                    # HIP runtime in use, say): the same collectives through torch.distributed's communicator
+                    import warnings
+                    warnings.warn(f"dbgsom_amd: RCCL inside the library is unavailable ({err}); "
+                                  "collectives go through torch.distributed")
+                    _RCCL_COMMS[self.device_index] = comm = None
+            if comm is not None:
+                _native.call("dbgsom_ctx_set_rccl", self._ctx, comm)
+                self._cb = None
+                return
         cache = {}   # the context reuses its stream and (until the map grows) its buffers
 
         def collective(_user, op, ptr, count, stream):

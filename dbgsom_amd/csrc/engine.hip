@@ -752,6 +752,8 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
     const bool remeasured = !isnan(c->arm_seen[row][p]);
     c->arm_known[row][p] = c->arm_seen[row][p] = mean;
     c->arm_age[row][p] = 0;
+    // (an arm that left more than the policy bears gets its next look late: a look at it costs an all-pairs epoch)
+    if (mean > (double)c->max_mean_candidates) c->arm_wait[row][p] = 128;
     if (!isnan(c->last_epoch_ms))   // (the mean of the last two looks: one epoch's clock jitters by a few per cent)
         c->arm_ms[row][p] = isnan(c->arm_ms[row][p]) ? c->last_epoch_ms : 0.5 * (c->arm_ms[row][p] + c->last_epoch_ms);
     if (c->last_probed) {  // what arm 0 would have produced from the same seeds
