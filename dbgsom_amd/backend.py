@@ -767,7 +767,7 @@ class HipBackend(HotPathBackend):
         return HipBackend(self.device_index, self.algorithm, _ctx=child)
 
     _SETTABLE = ("algorithm", "sweep_planes", "seed_stride", "timing", "graph", "refine", "defer",
-                 "filter_min_query_rows", "max_mean_candidates")
+                 "filter_min_query_rows", "max_mean_candidates", "shard_smooth")
 
     def release(self):
         """Give the device memory back (the backend can be loaded again afterwards; options stay)."""
