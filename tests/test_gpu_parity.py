@@ -720,6 +720,50 @@ def test_auto_policy_backs_off_on_near_duplicate_prototypes(o):
     assert be._get("guarded_calls") == n_tried               # every one of them stopped at its lists
 
 
+def test_auto_policy_on_unclustered_data_and_across_a_growth_step(o):
+    """Isotropic data in `auto` (the estimators' default): the first arm leaves the whole map a candidate --
+    it is on trial, so the call stops at its lists and all pairs find the winners (no exact stage over the whole
+    map); the next epochs go straight to the arms that can work (the winners as seeds, finer sweeps) instead of
+    backing off to all pairs, and settle on short lists.  A growth step (one more lattice column) keeps what
+    was learnt: no arm that failed is run again, nothing is on trial.  Results are exact throughout."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(21)
+    N, d, rows, cols = 30_000, 256, 20, 20
+    M = rows * cols
+    X = rng.normal(size=(N, d)).astype(np.float32)
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    hop = gi.lattice_hops(rows, cols)
+    be = HipBackend(algorithm="auto").load(X)
+    ex = HipBackend(algorithm="exact").load(X)
+    q = ex.epoch(W, hop, 3.0, 1e-3, "compact", True)
+    log = []
+    for e in range(8):
+        r = be.epoch(W, hop, 3.0, 1e-3, "compact", True)
+        assert np.array_equal(r.winners, q.winners) and np.array_equal(r.distances, q.distances)
+        assert np.array_equal(r.new_weights, q.new_weights, equal_nan=True)
+        log.append(be.filter_log[-1])
+    kinds, means = [entry[0] for entry in log], [entry[1] for entry in log]
+    assert kinds[0] == "filtered" and means[0] > 0.5 * M, log          # cheap seeds, coarse bound: (nearly) the whole map
+    n_guarded = be._get("guarded_calls")
+    assert n_guarded >= 1                                                # ... which stopped at its lists
+    assert "exact" not in kinds[:4], kinds                               # no back-off in front of the arms that can work
+    assert kinds[-1] == "filtered" and means[-1] < 0.25 * M, log         # settled on short lists
+    # one more lattice column: the same context carries on
+    cols2 = cols + 1
+    M2 = rows * cols2
+    W2 = np.concatenate([W, X[rng.choice(N, M2 - M, replace=False)].astype(np.float64)])
+    hop2 = gi.lattice_hops(rows, cols2)
+    q2 = ex.epoch(W2, hop2, 3.0, 1e-3, "compact", True)
+    for e in range(4):
+        r = be.epoch(W2, hop2, 3.0, 1e-3, "compact", True)
+        assert np.array_equal(r.winners, q2.winners) and np.array_equal(r.distances, q2.distances)
+        assert be.filter_log[-1][0] == "filtered" and be.filter_log[-1][1] < 0.25 * M2, be.filter_log[-4:]
+    assert be._get("guarded_calls") == n_guarded                         # nothing went on trial again
+    be.release()
+    ex.release()
+
+
 def test_seed_prepass_finds_the_informative_features(o):
     """Data whose information sits in two narrow feature ranges (everything else constant): the
     pre-pass samples the k-tiles in which the prototypes differ most, so the candidate lists stay
