@@ -1427,7 +1427,7 @@ int dbgsom_rccl_comm_destroy(void *comm) {
 int dbgsom_ctx_allreduce_host(dbgsom_ctx *c, double *vals_host, int64_t n) {
     CTX_CHECK(c);
     DBGSOM_REQUIRE(vals_host && n >= 1, "bad arguments");
-    if (!c->rccl_comm && !c->allreduce) return DBGSOM_OK;
+    if (!c->rccl_comm && !c->allreduce && !c->coll) return DBGSOM_OK;
     TRY(c->red.reserve((size_t)n * 8));
     DBGSOM_HIP_CHECK(hipMemcpyAsync(c->red.p, vals_host, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     TRY(run_allreduce(c, c->red.as<double>(), n));

@@ -58,6 +58,12 @@ def main():
         res[f"{tag}_shard_winners"] = rs.winners
         if tag == "filt":   # (two legs in the default form, one with the sharded smoothing still on)
             be.shard_smooth = 2
+            # small host vectors over the context's collective (what a caller without a communication
+            # library of its own uses around the epochs)
+            from dbgsom_amd import _native
+            v = np.array([rank + 1.0, 10.0, -0.5 * rank])
+            _native.call("dbgsom_ctx_allreduce_host", be._ctx, v.ctypes.data, v.size)
+            res["host_sum"] = v
         # a winner out of range on ONE rank must fail on EVERY rank (status rides in the reduced buffer)
         bad = r.winners.copy()
         if rank == 0:

@@ -91,6 +91,8 @@ def test_hip_backend_two_ranks_one_gpu(world, tmp_path):
             np.testing.assert_allclose(r[f"{tag}_shard_errors"], r1.errors, rtol=1e-12)
             np.testing.assert_allclose(r[f"{tag}_shard_change_total"], r1.change_total, rtol=1e-10)
         one.release()
+    for r in res:   # dbgsom_ctx_allreduce_host through the callback seam
+        assert np.array_equal(r["host_sum"], [world * (world + 1) / 2, 10.0 * world, -0.5 * world * (world - 1) / 2])
     # whole fits: replicated X == the reference's golden fit; per-rank shards == the same map
     name = "lowd_linear"
     g = gi.load(name)
