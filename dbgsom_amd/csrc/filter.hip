@@ -2206,6 +2206,10 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
     for (int u = 0; u < NS - 1; ++u)
         if (ntile > u) issue();
     int kt = 0, st = 0, r_stage = 0;
+    // 16-prototype tiles of the running step that hold list entries: the last step of a list is short (a
+    // 65-entry list in 48-entry steps: 48 + 17 -- two tiles, not three), tiles behind its end are skipped
+    int jtl_eff = JTL;
+    if constexpr (JTL > 1) { const int rem = (cnt + 15) / 16; jtl_eff = rem < JTL ? rem : JTL; }
 #if SUBSET_EXPERIMENT & 128
     t_loop = __builtin_amdgcn_s_memtime();
     __shared__ unsigned stamps[13 * 5];
@@ -2270,7 +2274,8 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
             }
 #endif
 #pragma unroll
-            for (int jt = 0; jt < JTL; ++jt)
+            for (int jt = 0; jt < JTL; ++jt) {
+                if (JTL > 1 && jt > 0 && jt >= jtl_eff) continue;   // (uniform: no entries in this tile)
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
 #if SUBSET_EXPERIMENT & 4
@@ -2279,6 +2284,7 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
                     acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt], b[it], acc[jt][it],
                                                                        0, 0, 0);
 #endif
+            }
         }
         STAMP(4);
         if (kt == nkt - 1) {
@@ -2314,6 +2320,10 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
                 for (int it = 0; it < IT; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
             kt = 0;
             ++st;
+            if constexpr (JTL > 1) {
+                const int rem = (cnt - st * SJ + 15) / 16;
+                jtl_eff = rem < JTL ? (rem < 1 ? 1 : rem) : JTL;
+            }
         } else {
             ++kt;
         }
