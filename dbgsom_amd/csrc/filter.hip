@@ -2275,7 +2275,7 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
 #endif
 #pragma unroll
             for (int jt = 0; jt < JTL; ++jt) {
-                if (JTL > 1 && jt > 0 && jt >= jtl_eff) continue;   // (uniform: no entries in this tile)
+                if (JTL > 1 && K == 1 && jt > 0 && jt >= jtl_eff) continue;   // (uniform: no entries in this tile)
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
 #if SUBSET_EXPERIMENT & 4
