@@ -2970,14 +2970,17 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         else DBGSOM_SUBSET_W(JTL, 4, STREAM);                                                     \
     } while (0)
     if (k2) {
+        // (8 wavefronts x 16 samples: with two (value, index) pairs per sample the 4 x 32 shape needed 256
+        //  registers for the long-list class and spilled in the others)
+        constexpr int K2_WAVES = 8;
 #define DBGSOM_SUBSET_K2(JTL, STREAM)                                                             \
     do {                                                                                          \
         if (x_dtype == DBGSOM_F32)                                                                \
-            hipLaunchKernelGGL((subset_exact_kernel<float, JTL, 4, 1, 2>), dim3((unsigned)f.nb), dim3(256), 0, STREAM, \
+            hipLaunchKernelGGL((subset_exact_kernel<float, JTL, K2_WAVES, 1, 2>), dim3((unsigned)f.nb), dim3(K2_WAVES * 64), 0, STREAM, \
                                (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
                                order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
         else                                                                                      \
-            hipLaunchKernelGGL((subset_exact_kernel<double, JTL, 4, 1, 2>), dim3((unsigned)f.nb), dim3(256), 0, STREAM, \
+            hipLaunchKernelGGL((subset_exact_kernel<double, JTL, K2_WAVES, 1, 2>), dim3((unsigned)f.nb), dim3(K2_WAVES * 64), 0, STREAM, \
                                (const double *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, \
                                order_dev, f.ulist, (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev); \
     } while (0)
