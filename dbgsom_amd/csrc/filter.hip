@@ -1817,7 +1817,7 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
 
 // the candidate lists of the 128-sample workgroups by the rule above.  count_only: only the sum of
 // the list lengths (into sum_out) -- what the lists WOULD be, for the engine's policy.
-__global__ __launch_bounds__(256) void prune_mark_kernel(
+__global__ __launch_bounds__(256, 6) void prune_mark_kernel(
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx, const double *__restrict__ xx, int64_t N, int d,
     int dpad, const int8_t *__restrict__ wplanes, int w_rows, const double *__restrict__ tw,
     const double *__restrict__ ww, const double *__restrict__ summary, int M,
@@ -1894,30 +1894,34 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(
         wrow[r] = wplanes + (size_t)(live[r] ? pj : 0) * FKT;
         wswz[r] = live[r] ? (pj >> 2) & 3 : 0;
     }
-    for (int ch0 = q; ch0 < nch; ch0 += 16) {
-        v4i_t xv[4][2], wv[4][2];
+    // (two of the thread's four samples at a time: 8 loads of 16 bytes in flight per thread, 64 registers for the
+    //  kernel -- eight workgroups per CU instead of four share the latency of its ~8 dependent steps)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+    for (int rh = 0; rh < 4; rh += 2)
+        for (int ch0 = q; ch0 < nch; ch0 += 16) {
+            v4i_t xv[2][2], wv[2][2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ch = ch0 + 8 * u;
-                const bool ok = live[r] && ch < nch;
-                const v4i_t zero = {0, 0, 0, 0};
-                xv[r][u] = ok ? *reinterpret_cast<const v4i_t *>(xrow[r] + ch * 16) : zero;
-                wv[r][u] = ok ? *reinterpret_cast<const v4i_t *>(wrow[r] + (size_t)(ch >> 2) * w_rows * FKT +
-                                                                 (((ch & 3) ^ wswz[r]) << 4)) : zero;
-            }
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a0r[r] = __builtin_amdgcn_sdot4(xv[r][u][e], wv[r][u][e], a0r[r], false);
-                    axr[r] = __builtin_amdgcn_sdot4(xv[r][u][e], xv[r][u][e], axr[r], false);
-                    awr[r] = __builtin_amdgcn_sdot4(wv[r][u][e], wv[r][u][e], awr[r], false);
+                for (int u = 0; u < 2; ++u) {
+                    const int ch = ch0 + 8 * u;
+                    const bool ok = live[rh + r] && ch < nch;
+                    const v4i_t zero = {0, 0, 0, 0};
+                    xv[r][u] = ok ? *reinterpret_cast<const v4i_t *>(xrow[rh + r] + ch * 16) : zero;
+                    wv[r][u] = ok ? *reinterpret_cast<const v4i_t *>(wrow[rh + r] + (size_t)(ch >> 2) * w_rows * FKT +
+                                                                     (((ch & 3) ^ wswz[rh + r]) << 4)) : zero;
                 }
-    }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a0r[rh + r] = __builtin_amdgcn_sdot4(xv[r][u][e], wv[r][u][e], a0r[rh + r], false);
+                        axr[rh + r] = __builtin_amdgcn_sdot4(xv[r][u][e], xv[r][u][e], axr[rh + r], false);
+                        awr[rh + r] = __builtin_amdgcn_sdot4(wv[r][u][e], wv[r][u][e], awr[rh + r], false);
+                    }
+        }
 #pragma unroll
     for (int round = 0; round < 4; ++round) {
         const int il = round * 32 + (tid >> 3);
