@@ -410,10 +410,22 @@ def run_via_ctx(args):
 
     try:
         if world > 1 or os.environ.get("DBGSOM_FORCE_COLLECTIVE") == "1":
-            path = os.path.join(tempfile.gettempdir(), "dbgsom_rccl_%s_%s.id" % (
-                os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run")))
+            # the id travels through a file named after THIS launch: the ranks share their launcher (torchrun's agent,
+            # or whoever started them), so its pid and start time are a nonce every rank can compute and no earlier
+            # run can have used; rank 0 also removes whatever may lie there before it writes
+            ppid = os.getppid()
+            try:
+                with open("/proc/%d/stat" % ppid) as fh:
+                    born = fh.read().rsplit(")", 1)[1].split()[19]
+            except OSError:
+                born = "0"
+            path = os.path.join(tempfile.gettempdir(), "dbgsom_rccl_%s_%s_%d_%s.id" % (
+                os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run"), ppid, born))
             uid = ctypes.create_string_buffer(128)
             if rank == 0:
+                for stale in (path, path + ".tmp"):
+                    if os.path.exists(stale):
+                        os.unlink(stale)
                 nat.call("dbgsom_rccl_unique_id", uid)
                 with open(path + ".tmp", "wb") as fh:
                     fh.write(uid.raw)

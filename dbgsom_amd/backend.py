@@ -200,7 +200,8 @@ class _DeviceArray:
                                          "data": (int(ptr), False), "version": 3, "strides": None}
 
 
-_RCCL_COMMS = {}   # device index -> ncclComm_t made by dbgsom_rccl_comm_init (process lifetime)
+_RCCL_COMMS = {}   # (device index, world, rank) -> ncclComm_t made by dbgsom_rccl_comm_init (process lifetime;
+                    # a process group rebuilt with another size or rank gets a communicator of its own)
 
 
 class HipBackend(HotPathBackend):
@@ -295,7 +296,7 @@ class HipBackend(HotPathBackend):
     refine = property(lambda self: self._get("refine"), lambda self, v: self._set("refine", int(v)))
     refined = property(lambda self: bool(self._get("refined")))   # what the last filtered search ran
     # with the refinement: the distance of a sample it decided is evaluated inside the sums kernel of the
-    # epoch (one pass over the float rows for distance and sums) -- 1 (default) / 0
+    # epoch (one pass over the float rows for distance and sums) -- 1 / 0 (the engine's default: experimental, off)
     defer = property(lambda self: bool(self._get("defer")), lambda self, v: self._set("defer", int(bool(v))))
     # neighbourhood smoothing sharded over the ranks (reduce-scatter of column blocks of the sums, all-gather of
     # the new prototypes): 0 never, 1 whenever the collective can, 2 (default) on large maps
@@ -331,7 +332,8 @@ class HipBackend(HotPathBackend):
             # RCCL driven by the library itself (dbgsom_ctx_set_rccl): no callback, no interpreter in the
             # epoch.  One communicator per process and device, made once (torch.distributed only carries
             # rank 0's 128-byte id to the other ranks) and shared by every context of this process.
-            comm = _RCCL_COMMS.get(self.device_index, "untried")
+            key = (self.device_index, world, rank)
+            comm = _RCCL_COMMS.get(key, "untried")
             if comm == "untried":
                 # (every rank goes through every step and the ranks then agree on the outcome: a communicator
                 #  that came up on some ranks only must not be used by any)
@@ -356,14 +358,14 @@ class HipBackend(HotPathBackend):
                 ok = torch.tensor([1 if (err is None and comm.value) else 0], device=dev, dtype=torch.int32)
                 td.all_reduce(ok, op=td.ReduceOp.MIN)
                 if int(ok.item()) == 1:
-                    _RCCL_COMMS[self.device_index] = comm
+                    _RCCL_COMMS[key] = comm
                 else:
                     # the library could not drive RCCL itself in this process (its librccl is not the one of the
                     # HIP runtime in use, say): the same collectives through torch.distributed's communicator
                     import warnings
                     warnings.warn(f"dbgsom_amd: RCCL inside the library is unavailable ({err}); "
                                   "collectives go through torch.distributed")
-                    _RCCL_COMMS[self.device_index] = comm = None
+                    _RCCL_COMMS[key] = comm = None
             if comm is not None:
                 _native.call("dbgsom_ctx_set_rccl", self._ctx, comm)
                 self._cb = None

@@ -160,7 +160,7 @@ int launch_smooth(const double *sums, int64_t M, int64_t d, const float *hop, do
                   int layout, const double *W_old, double *W_new, double *change_total, void *ws,
                   size_t ws_bytes, hipStream_t s);
 // smoothing sharded over the ranks (smooth.hip): column blocks of cb = smooth_block_cols columns; one block
-// of the reduce-scatter buffer = [S block (M x cb) | K | a | E | status | pad] = smooth_block_elems values
+// of the reduce-scatter buffer = S block (M x cb) = smooth_block_elems values; [K | a | E | status] stay in `sums`
 int64_t smooth_block_cols(int64_t d, int nranks);
 int64_t smooth_block_elems(int64_t M, int64_t d, int nranks);
 int launch_pack_blocks(const double *sums, int64_t M, int64_t d, int nranks, double *out, hipStream_t s);

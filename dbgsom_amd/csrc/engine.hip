@@ -607,15 +607,17 @@ int rccl_load() {
     }
     g_rccl.tried = true;
     void *h = nullptr;
-    // a copy already in the process (PyTorch's) shares the HIP runtime that is in use: take it
-    if (dlsym(RTLD_DEFAULT, "ncclAllReduce")) h = RTLD_DEFAULT;
+    // a copy already in the process (PyTorch's) shares the HIP runtime that is in use: take it.  RTLD_DEFAULT is a
+    // null pointer on glibc, so "found in the process" is a flag of its own, not a non-null handle
+    const bool in_process = dlsym(RTLD_DEFAULT, "ncclAllReduce") != nullptr;
+    if (in_process) h = RTLD_DEFAULT;
     const char *env = getenv("DBGSOM_RCCL_LIB");
     const char *names[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char *n : names) {
-        if (h) break;
+        if (in_process || h) break;
         if (n && *n) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     }
-    if (!h) { set_error("librccl not found (set DBGSOM_RCCL_LIB): %s", dlerror()); return DBGSOM_ESTATE; }
+    if (!h && !in_process) { set_error("librccl not found (set DBGSOM_RCCL_LIB): %s", dlerror()); return DBGSOM_ESTATE; }
     g_rccl.get_unique_id = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
     g_rccl_init = (nccl_comm_init_rank_fn)dlsym(h, "ncclCommInitRank");
     g_rccl.all_reduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
@@ -973,17 +975,17 @@ int accumulate_and_reduce(dbgsom_ctx *c, const int64_t *idx, const double *kw, d
     c->sumsM = M;
     c->sums_sharded = false;
     if (shard_smoothing(c, M, s.dp)) {
-        // column blocks [S block | K | a | E | status] -> reduce-scatter: this rank's block holds the sums of all
-        // ranks for the columns it smooths, and the small vectors in full (copied behind the local S so that
-        // everything downstream finds K, a, E and the status flag where it always does)
+        // column blocks of S -> reduce-scatter: this rank's block holds the sums of all ranks for the columns it
+        // smooths.  The small vectors [K | a | E | status] behind S go through an ordinary all-reduce where they lie:
+        // growth and convergence are decided from them on every rank, so they must be the same bits everywhere (a
+        // reduce-scatter sums each block along its own chain of ranks)
         const int G = c->coll_nranks;
-        const int64_t cb = smooth_block_cols(s.dp, G), blk = smooth_block_elems(M, s.dp, G);
+        const int64_t blk = smooth_block_elems(M, s.dp, G);
         TRY(c->shard_send.reserve((size_t)G * blk * 8));
         double *send = c->shard_send.as<double>();
         TRY(launch_pack_blocks(c->sums.as<double>(), M, s.dp, G, send, c->stream));
+        TRY(run_allreduce(c, c->sums.as<double>() + (size_t)M * s.dp, 3 * M + 1));
         TRY(run_block_collective(c, DBGSOM_COLL_REDUCE_SCATTER, send, blk));
-        DBGSOM_HIP_CHECK(hipMemcpyAsync(c->sums.as<double>() + (size_t)M * s.dp, send + (size_t)c->coll_rank * blk + (size_t)M * cb,
-                                        (size_t)(3 * M + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
         c->sums_sharded = true;
         c->sumsM = 0;   // (the S part of `sums` is this rank's share, not the reduced sums: nothing to read back)
         return DBGSOM_OK;
@@ -1013,7 +1015,7 @@ int smooth_and_fetch(dbgsom_ctx *c, int64_t M, double sigma, int layout, int fla
         const double *mine = c->shard_send.as<double>() + (size_t)r * blk;
         TRY(c->shard_gather.reserve((size_t)G * M * cb * 8));
         double *gather = c->shard_gather.as<double>();
-        TRY(launch_smooth_block(mine, mine + (size_t)M * cb, mine + (size_t)M * cb + M, M, cb, dp, c->hop.as<float>(), sigma,
+        TRY(launch_smooth_block(mine, sums + (size_t)M * dp, sums + (size_t)M * dp + M, M, cb, dp, c->hop.as<float>(), sigma,
                                 layout, gather + (size_t)r * M * cb, c->sm_ws.p, c->sm_ws.cap, c->stream));
         TRY(run_block_collective(c, DBGSOM_COLL_ALLGATHER, gather, M * cb));
         TRY(launch_rowchange_blocks(gather, M, dp, cb, c->Wb[c->cur].as<double>(), c->Wb[nxt].as<double>(), chg, c->sm_ws.p,
@@ -1633,7 +1635,7 @@ int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f
             ++r.n[measuring];
         }
         c->last_frozen = (flags & DBGSOM_EPOCH_FROZEN) != 0;
-        c->last_epoch_ms = (c->last_filtered && !c->last_probed && !c->last_guarded && measuring < 0 && !W_new_host && !idx_host && !dist_host)
+        c->last_epoch_ms = (c->last_filtered && !c->last_probed && !c->last_guarded && !c->last_retry && measuring < 0 && !W_new_host && !idx_host && !dist_host)
                                ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()
                                : NAN;
         update_policy(c, c->tail.as<double>()[2 * M + 2], c->tail.as<double>()[2 * M + 3], c->tail.as<double>()[2 * M + 4],

@@ -396,26 +396,22 @@ __global__ __launch_bounds__(256) void rowchange_kernel(const double *__restrict
 // ---- smoothing sharded over the ranks of a sample-sharded job (columns of W') -------------------
 // W'[:, c] depends on column c of the centres and on nothing else of S, so rank r of G smooths the
 // columns [r cb, (r + 1) cb) only: the epoch's collective becomes a reduce-scatter of column blocks
-// [S[:, block] | K | a | E | status] (every rank then holds the reduced block it smooths and the small
-// vectors in full), the GEMM shrinks to M x M x cb per rank, and an all-gather of the W' blocks gives every
+S[:, block] (every rank then holds the reduced block it smooths; the small vectors [K | a | E | status] are
+// all-reduced beside it, bit-identical on every rank), the GEMM shrinks to M x M x cb per rank, and an all-gather of the W' blocks gives every
 // rank the same W' bit for bit.  The k range is cut as for the whole matrix (gemm_splits of the FULL
 // shape), so a column of W' is the same chain of the same pieces in either form.
 
-// [nblk][ S block (M x cb) | tail (tailn) ] from the row-major sums [S (M x d) | tail]; columns behind d: 0
+// [nblk][ S block (M x cb) ] from the row-major sums [S (M x d) | tail]; columns behind d: 0.  The small vectors
+// [K | a | E | status] are NOT part of a block: a reduce-scatter gives every block its own summation chain, so
+// copies of them riding in the blocks could differ in the last bit from rank to rank; they go through one
+// ordinary all-reduce instead (engine.hip), whose result is the same on every rank.
 __global__ __launch_bounds__(256) void pack_blocks_kernel(const double *__restrict__ sums, int M, int d, int cb,
-                                                          int nblk, int64_t blk, int tail_count,
-                                                          double *__restrict__ out) {
+                                                          int nblk, int64_t blk, double *__restrict__ out) {
     const int i = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
     double *dst = out + (size_t)b * blk;
-    if (i < M) {
-        for (int cc = t; cc < cb; cc += 256) {
-            const int c = b * cb + cc;
-            dst[(size_t)i * cb + cc] = c < d ? sums[(size_t)i * d + c] : 0.0;
-        }
-    } else {   // (workgroups M ..: the tail, 256 values each)
-        const int e = (i - M) * 256 + t;
-        const int64_t tailn = blk - (int64_t)M * cb;
-        if (e < tailn) dst[(size_t)M * cb + e] = e < tail_count ? sums[(size_t)M * d + e] : 0.0;
+    for (int cc = t; cc < cb; cc += 256) {
+        const int c = b * cb + cc;
+        dst[(size_t)i * cb + cc] = c < d ? sums[(size_t)i * d + c] : 0.0;
     }
 }
 
@@ -474,14 +470,13 @@ int64_t smooth_block_cols(int64_t d, int nranks) {
     return (cb + 1) / 2 * 2;   // (16-byte rows for the GEMM's LDS-DMA)
 }
 int64_t smooth_block_elems(int64_t M, int64_t d, int nranks) {
-    return M * smooth_block_cols(d, nranks) + (3 * M + 1 + 1) / 2 * 2;
+    return M * smooth_block_cols(d, nranks);
 }
 
 int launch_pack_blocks(const double *sums, int64_t M, int64_t d, int nranks, double *out, hipStream_t s) {
     const int64_t cb = smooth_block_cols(d, nranks), blk = smooth_block_elems(M, d, nranks);
-    const int64_t tailn = blk - M * cb;
-    hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)(M + (tailn + 255) / 256), (unsigned)nranks), dim3(256), 0, s, sums,
-                       (int)M, (int)d, (int)cb, nranks, blk, (int)(3 * M + 1), out);
+    hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)M, (unsigned)nranks), dim3(256), 0, s, sums, (int)M, (int)d, (int)cb,
+                       nranks, blk, out);
     return launch_status("pack_blocks_kernel");
 }
 

@@ -326,9 +326,11 @@ int dbgsom_ctx_set_rccl(dbgsom_ctx *ctx, void *nccl_comm);
  *                               block holds its owner's (ncclAllGather(buf + rank * count, buf, count))
  * With the last two (or with RCCL, dbgsom_ctx_set_rccl) the epoch can shard the neighbourhood smoothing
  * (BaseSom.py:509-515) over the ranks: column c of the new prototypes needs column c of the Voronoi sums and
- * nothing else of them, so the sums are reduce-scattered as column blocks [S block | K | a | E | status], each
- * rank smooths its d / nranks columns, and an all-gather of the blocks leaves the same W' on every rank bit for
- * bit -- the same bytes on the wire as the all-reduce, 1 / nranks of the M x M x d product per rank.  Option
+ * nothing else of them, so S is reduce-scattered as column blocks, the small vectors [K | a | E | status]
+ * (3 M + 1 values: what growth and convergence are decided from) are all-reduced so that every rank holds the
+ * same bits of them, each rank smooths its d / nranks columns, and an all-gather of the blocks leaves the same
+ * W' on every rank bit for bit -- the bytes of the all-reduce on the wire, 1 / nranks of the M x M x d product
+ * per rank.  Option
  * "shard_smooth": 0 never, 1 whenever the collective can, 2 (default) from ~8 GFLOP of smoothing (2 M^2 d).
  * Results equal the replicated form's bit for bit whenever the reduced sums do (two ranks: always). */
 enum { DBGSOM_COLL_ALLREDUCE = 0, DBGSOM_COLL_REDUCE_SCATTER = 1, DBGSOM_COLL_ALLGATHER = 2 };

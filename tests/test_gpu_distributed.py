@@ -83,6 +83,10 @@ def test_hip_backend_two_ranks_one_gpu(world, tmp_path):
             assert np.array_equal(r[f"{tag}_shard_new_weights"], res[0][f"{tag}_shard_new_weights"])
             assert np.array_equal(r[f"{tag}_shard_winners"], r[f"{tag}_winners"])
             assert np.array_equal(r[f"{tag}_shard_activations"], r1.activations)
+            # what growth and convergence are decided from is the same on every rank, bit for bit, in both forms
+            # and for any number of ranks (the small vectors are all-reduced, never reduce-scattered)
+            for key in ("errors", "activations", "change_total", "shard_errors", "shard_activations", "shard_change_total"):
+                assert np.array_equal(r[f"{tag}_{key}"], res[0][f"{tag}_{key}"]), (tag, key)
             if world == 2:
                 assert np.array_equal(r[f"{tag}_shard_new_weights"], r[f"{tag}_new_weights"])
                 assert float(r[f"{tag}_shard_change_total"]) == float(r[f"{tag}_change_total"])
@@ -187,3 +191,4 @@ def test_sharded_smoothing_blocks_equal_the_replicated_form(G, d, rows, cols, la
                 assert res.change_total == ref.change_total
             be.release()
     assert ops.count(_native.COLL_REDUCE_SCATTER) == 2 * G and ops.count(_native.COLL_ALLGATHER) == 2 * G
+    assert ops.count(_native.COLL_ALLREDUCE) == 2 * G      # the small vectors [K | a | E | status], beside the blocks
