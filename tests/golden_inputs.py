@@ -40,6 +40,11 @@ def case_X(name):
         from sklearn.datasets import make_blobs
 
         return make_blobs(n_samples=3000, n_features=16, centers=8, random_state=1)[0], None
+    if name in ("grow_blobs_f32", "grow_blobs_f64", "grow_dup_f64"):
+        from sklearn.datasets import make_blobs
+
+        X = make_blobs(n_samples=20000, n_features=32, centers=200, random_state=4 if name == "grow_blobs_f64" else 3)[0]
+        return X.astype(np.float32 if name.endswith("f32") else np.float64), None
     if name == "lowd_linear":
         return np.random.default_rng(5).normal(size=(2000, 3)) * np.array([3.0, 1.0, 0.3]), None
     if name == "ties_int":
@@ -60,7 +65,13 @@ def case_X(name):
 
 
 FIT_CASES = ["digits_f64", "digits_f32", "blobs_dead", "lowd_linear", "ties_int", "digits_clf",
-             "digits_entropy"]
+             "digits_entropy", "grow_blobs_f32", "grow_blobs_f64"]
+# fits of the reference that grow past the 128 prototypes from which the build's default search is the filtered one
+# (up to 247 / 221 neurons, a third of them dead at the end): the estimator's default path inside a growing fit
+GROW_CASES = ["grow_blobs_f32", "grow_blobs_f64"]
+# a fit of the same kind in which two dead neurons at the same hop distances from every live one become bit-identical prototypes (epoch 43) and the reference's
+# BLAS splits the exact ties of epoch 44 between them: reproduced up to the tie, see tools/make_golden.py GROW_CASES
+DUP_CASE, DUP_EPOCH, DUP_ROWS = "grow_dup_f64", 44, (175, 194)
 CLF_CASES = ("digits_clf", "digits_entropy")
 FROZEN_CASES = ["frozen_c2_f32", "frozen_c3_f32", "frozen_f64"]
 
@@ -74,6 +85,9 @@ EST_KWARGS = {
                         spreading_factor=0.3, sigma_start=2.0, sigma_end=0.5,
                         coarse_training_frac=0.6, convergence_iter=3),
     "ties_int": dict(random_state=1, n_iter=12, max_neurons=30),
+    "grow_blobs_f32": dict(random_state=0, max_neurons=300, spreading_factor=0.9, n_iter=120, convergence_iter=2),
+    "grow_blobs_f64": dict(random_state=0, max_neurons=300, spreading_factor=0.9, n_iter=100, convergence_iter=2),
+    "grow_dup_f64": dict(random_state=0, max_neurons=260, spreading_factor=0.95, n_iter=100, convergence_iter=2),
     "digits_entropy": dict(random_state=0, n_iter=30, growth_criterion="entropy",
                            spreading_factor=0.4, max_neurons=40),
     "vertical_blobs": dict(random_state=2, vertical_growth=True, n_iter=24, max_neurons=9,

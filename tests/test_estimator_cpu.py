@@ -44,7 +44,10 @@ def test_full_fit_matches_reference(name):
     assert np.array_equal(tr[:, 0].astype(int), g["trace_n_neurons"])
     np.testing.assert_allclose(tr[:, 1], g["trace_sigma"], rtol=1e-15)
     assert np.array_equal(tr[:, 4].astype(int), g["trace_n_dead"])
-    np.testing.assert_allclose(tr[:, 2], g["trace_weights_sum"], rtol=1e-9)
+    # (atol: epoch 0 of a float32 fit returns distances rounded through float32 -- BaseSom.py:455-457 with float32
+    #  prototypes -- and of 20 000 samples a few sit on a rounding boundary that BLAS order and chain order resolve
+    #  differently: 4e-8 on a sum of 15 at epoch 0 of grow_blobs_f32, 1e-11 from epoch 2 on)
+    np.testing.assert_allclose(tr[:, 2], g["trace_weights_sum"], rtol=1e-9, atol=1e-7)
     # fitted attributes
     assert est.n_iter_ == int(g["final_n_iter"])
     assert est.converged_ == bool(g["final_converged"])
@@ -75,6 +78,23 @@ def test_full_fit_matches_reference(name):
             g["final_node_probabilities"], rtol=1e-12)
         assert np.array_equal(est.predict(X), g["final_predict"])
         assert est.score(X, y) == float(g["final_score"])
+
+
+def test_fit_reproduces_the_reference_up_to_its_blas_dependent_tie():
+    """grow_dup_f64: the reference's fit in which bit-identical prototypes appear at epoch 43 (see
+    test_oracle_golden.test_reference_splits_exact_ties_between_duplicate_prototypes).  Up to and including the epoch
+    of the tie the host logic and the hot path follow the recorded trace (map sizes, sigma, dead neurons; the
+    prototypes until the tie changes them); afterwards the reference runs on with its BLAS's split of the ties."""
+    g = gi.load(gi.DUP_CASE)
+    est, be, X, _ = _fit(gi.DUP_CASE)
+    tr = np.array(be.trace)
+    e = gi.DUP_EPOCH
+    assert np.array_equal(tr[:e + 1, 0].astype(int), g["trace_n_neurons"][:e + 1])
+    np.testing.assert_allclose(tr[:e + 1, 1], g["trace_sigma"][:e + 1], rtol=1e-15)
+    assert np.array_equal(tr[:e, 4].astype(int), g["trace_n_dead"][:e])
+    np.testing.assert_allclose(tr[:e, 2], g["trace_weights_sum"][:e], rtol=1e-9, atol=1e-7)
+    # the tie itself: one more dead neuron here (the higher of the two names never wins), none of the two in the reference
+    assert int(tr[e, 4]) == int(g["trace_n_dead"][e]) + 1
 
 
 def test_growth_trace_node_by_node():

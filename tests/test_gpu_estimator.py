@@ -42,6 +42,57 @@ def test_fit_on_gpu_matches_reference(name):
         assert est.score(X, y) == float(g["final_score"])
 
 
+@pytest.mark.parametrize("mode", ["default", "filtered", "refine", "prune"])
+@pytest.mark.parametrize("name", gi.GROW_CASES)
+def test_growing_fit_through_the_filtered_search_matches_the_reference(name, mode):
+    """Fits the REFERENCE ran (tools/make_golden.py GROW_CASES; its loop BaseSom.py:387-417, growth :411-417,
+    :588-614) that grow to 247 / 224 neurons with up to a third of them dead: from 129 prototypes on the estimator's
+    default search is the filtered one (previous winners as seeds, the engine's arms, growth steps on the resident
+    prototypes).  The whole fit must end in the recorded map -- default backend; the stateless filtered form; the
+    per-sample refinement forced on; the pruning form forced -- and the log must show that the filtered search ran."""
+    from dbgsom_amd import SomVQ
+    from dbgsom_amd.backend import HipBackend
+
+    g = gi.load(name)
+    X, _ = gi.case_X(name)
+    if mode == "default":
+        est = SomVQ(**gi.EST_KWARGS[name])
+    else:
+        be = HipBackend(algorithm={"filtered": "filtered", "refine": "auto", "prune": "filtered_hint"}[mode])
+        if mode == "refine":
+            be.refine = 1
+        if mode == "prune":
+            be.sweep_planes = 4
+        est = SomVQ(backend=be, **gi.EST_KWARGS[name])
+    log = []
+    be = est._engine()
+    assert isinstance(be, HipBackend) and be.algorithm == ("auto" if mode == "default" else be.algorithm)
+    orig = be._log_epoch
+
+    def spy():
+        orig()
+        log.append((be._last_M,) + tuple(be.filter_log[-1]) + (be.refined,))
+
+    be._log_epoch = spy
+    est.fit(X)
+    assert est.n_iter_ == int(g["final_n_iter"])
+    assert [tuple(n) for n in g["final_neurons"]] == est.neurons_
+    np.testing.assert_allclose(est.weights_, g["final_weights"], rtol=1e-8, atol=1e-10)
+    assert np.array_equal(est.labels_, g["final_labels"])             # BMU indices bit-exact
+    np.testing.assert_allclose(est.quantization_error_, float(g["final_qe"]), rtol=1e-10)
+    assert est.topographic_error_ == float(g["final_te"])
+    sizes = [e[0] for e in log]
+    assert sizes == [int(m) for m in g["trace_n_neurons"]]             # the recorded map size, epoch by epoch
+    big = [e for e in log if e[0] >= HipBackend.FILTER_MIN_PROTOTYPES]
+    filt = [e for e in big if e[1] == "filtered"]
+    assert len(big) >= 60 and len(filt) >= (len(big) if mode != "default" and mode != "refine" else len(big) // 2), \
+        (len(big), len(filt))
+    if mode == "refine":
+        assert any(e[-1] for e in filt), "the refinement never ran"
+    if mode == "prune":
+        assert all(e[3] == 0 for e in filt)                            # no sweep: candidates by the triangle inequality
+
+
 def test_known_answers_digits_gpu():
     from dbgsom_amd import SomVQ
 

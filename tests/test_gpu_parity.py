@@ -118,7 +118,7 @@ def test_golden_epochs(hip, o, name):
         assert np.array_equal(res.winners, g[f"e{e}_winners"]), (name, e)
         xn = float(np.max(np.einsum("ij,ij->i", X, X, dtype=np.float64)))
         np.testing.assert_allclose(res.distances ** 2, g[f"e{e}_distances"] ** 2,
-                                   rtol=1e-7 if W.dtype == np.float32 else 1e-9, atol=1e-12 * xn)
+                                   rtol=3e-7 if W.dtype == np.float32 else 1e-9, atol=1e-12 * xn)
         assert np.array_equal(res.activations, g[f"e{e}_activations"])
         if f"e{e}_errors" in g:
             np.testing.assert_allclose(res.errors, g[f"e{e}_errors"], rtol=1e-9, atol=1e-6)
@@ -133,6 +133,42 @@ def test_golden_epochs(hip, o, name):
                                    equal_nan=True)
         np.testing.assert_allclose(res.errors, oo.errors, rtol=1e-12)
         np.testing.assert_allclose(res.change_total, oo.change_total, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("algo", ["exact", "filtered", "prune"])
+def test_reference_tie_between_duplicate_prototypes(o, algo):
+    """grow_dup_f64, epoch 44 (see tests/test_oracle_golden.py): two bit-identical prototype rows (175, 194), 389
+    samples nearest to them.  Every form of the search gives them to the LOWER index, with the chain's distances;
+    the reference's BLAS splits them between the two.  Everything else equals the recorded epoch."""
+    from dbgsom_amd.backend import HipBackend
+
+    g = gi.load(gi.DUP_CASE)
+    X, _ = gi.case_X(gi.DUP_CASE)
+    e, (a, b) = gi.DUP_EPOCH, gi.DUP_ROWS
+    W, hop = g[f"e{e}_weights_in"], g[f"e{e}_hop_distance"]
+    assert np.array_equal(W[a], W[b]) and W.shape[0] >= HipBackend.FILTER_MIN_PROTOTYPES
+    be = HipBackend(0, algorithm="filtered" if algo == "prune" else algo).load(X)
+    if algo == "prune":
+        be.sweep_planes = 4
+    gamma = float(g[f"e{e}_total_variance"] ** -1)
+    res = be.epoch(W, hop, float(g[f"e{e}_sigma"]), gamma, "compact", True)
+    if algo != "exact":
+        assert be.filter_log[-1][0] == "filtered"
+    gw = g[f"e{e}_winners"]
+    assert not (res.winners == b).any()
+    assert np.array_equal(res.winners, np.where(gw == b, a, gw))
+    oo = o.epoch(X, W, hop, float(g[f"e{e}_sigma"]), g[f"e{e}_total_variance"], "compact", "chain")
+    assert np.array_equal(res.winners, oo.winners) and np.array_equal(res.distances, oo.distances)
+    np.testing.assert_allclose(res.new_weights, oo.new_weights, rtol=1e-11, atol=1e-12, equal_nan=True)
+    d2, i2 = be.bmu(W, 2)
+    tied = res.winners == a
+    assert (i2[tied] == [a, b]).all() and (d2[tied, 0] == d2[tied, 1]).all()
+    # the epochs before the tie are the reference's, winners bit for bit
+    for e0 in (0, 30, 43):
+        r0 = be.epoch(g[f"e{e0}_weights_in"], g[f"e{e0}_hop_distance"], float(g[f"e{e0}_sigma"]), gamma, "compact", True)
+        assert np.array_equal(r0.winners, g[f"e{e0}_winners"]), e0
+        np.testing.assert_allclose(r0.new_weights, g[f"e{e0}_weights_out"], rtol=1e-7, atol=1e-9, equal_nan=True)
+    be.release()
 
 
 @pytest.mark.parametrize("name", gi.FROZEN_CASES)

@@ -388,6 +388,42 @@ def run_frozen_case(name, X, rows, cols, seed, wdtype):
     return meta
 
 
+GROW_CASES = {
+    # fits that grow well past the 128 prototypes below which the build's default search is the all-pairs kernel
+    # (dbgsom_amd/backend.py FILTER_MIN_PROTOTYPES): the reference's own loop, BaseSom.py:387-417, growth steps
+    # :411-417 / :588-614, with a third of the final lattice dead at the end (deleted, :119)
+    "grow_blobs_f32": dict(
+        X="make_blobs(n_samples=20000, n_features=32, centers=200, random_state=3)[0].astype(float32)",
+        data_seed=3, dtype=np.float32,
+        kw=dict(random_state=0, max_neurons=300, spreading_factor=0.9, n_iter=120, convergence_iter=2),
+        epochs=[0, 27, 40, 58, 90, 118]),
+    "grow_blobs_f64": dict(
+        X="make_blobs(n_samples=20000, n_features=32, centers=200, random_state=4)[0] (float64)",
+        data_seed=4, dtype=np.float64,
+        kw=dict(random_state=0, max_neurons=300, spreading_factor=0.9, n_iter=100, convergence_iter=2),
+        epochs=[0, 30, 52, 98]),
+    # the same kind of fit on other blobs: at epoch 43 two dead neurons of the lattice (the same hop distance to every
+    # LIVE neuron, own hit count 0) leave the smoothing as bit-identical rows (175 and 194),
+    # and at epoch 44 the 389 samples nearest to them are EXACT ties.  The reference's winner among the two is
+    # whatever its BLAS's summation order gives each column of the GEMM (here: 271 samples to 194, 118 to 175) -- not
+    # a property of the algorithm.  Recorded to pin exactly that: everything up to the tie is reproduced, and at the
+    # tie the reference's winners differ from lowest-index-wins only between bit-identical prototypes.
+    "grow_dup_f64": dict(
+        X="make_blobs(n_samples=20000, n_features=32, centers=200, random_state=3)[0] (float64)",
+        data_seed=3, dtype=np.float64,
+        kw=dict(random_state=0, max_neurons=260, spreading_factor=0.95, n_iter=100, convergence_iter=2),
+        epochs=[0, 30, 43, 44]),
+}
+
+
+def run_grow_case(name):
+    c = GROW_CASES[name]
+    X = make_blobs(n_samples=20000, n_features=32, centers=200, random_state=c["data_seed"])[0].astype(c["dtype"])
+    kw = c["kw"]
+    return run_fit_case(name, lambda: SomVQ(**kw), X, None, c["epochs"],
+                        {"X": c["X"], "est": "SomVQ(%s)" % ", ".join(f"{k}={v!r}" for k, v in kw.items())})
+
+
 def main():
     only = set(sys.argv[1:])
     mpath = os.path.join(OUT, "manifest.json")
@@ -419,6 +455,9 @@ def main():
              "est": "SomVQ(random_state=2, vertical_growth=True, n_iter=24, max_neurons=9, "
                     "min_samples_vertical_growth=150, spreading_factor=0.6)"},
         )
+    for name in GROW_CASES:
+        if not only or name in only:
+            manifest["cases"][name] = run_grow_case(name)
     if only:
         with open(mpath, "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
