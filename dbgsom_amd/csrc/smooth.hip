@@ -396,9 +396,9 @@ __global__ __launch_bounds__(256) void rowchange_kernel(const double *__restrict
 // ---- smoothing sharded over the ranks of a sample-sharded job (columns of W') -------------------
 // W'[:, c] depends on column c of the centres and on nothing else of S, so rank r of G smooths the
 // columns [r cb, (r + 1) cb) only: the epoch's collective becomes a reduce-scatter of column blocks
-S[:, block] (every rank then holds the reduced block it smooths; the small vectors [K | a | E | status] are
-// all-reduced beside it, bit-identical on every rank), the GEMM shrinks to M x M x cb per rank, and an all-gather of the W' blocks gives every
-// rank the same W' bit for bit.  The k range is cut as for the whole matrix (gemm_splits of the FULL
+// S[:, block] (every rank then holds the reduced block it smooths; the small vectors [K | a | E | status] are
+// all-reduced beside it, bit-identical on every rank), the GEMM shrinks to M x M x cb per rank, and an
+// all-gather of the W' blocks gives every rank the same W' bit for bit.  The k range is cut as for the whole matrix (gemm_splits of the FULL
 // shape), so a column of W' is the same chain of the same pieces in either form.
 
 // [nblk][ S block (M x cb) ] from the row-major sums [S (M x d) | tail]; columns behind d: 0.  The small vectors
