@@ -124,22 +124,28 @@ def make_shard(torch, n, d, seed, device, rank=0, kind="blobs"):
     return X
 
 
+def iter_shard_numpy(n, d, seed, kind="blobs", rank=0, step=100_000):
+    """The rows of make_shard_numpy in chunks of `step` (the stream is consumed chunk by chunk, so the chunks ARE
+    the rows of the whole array): (first row, float32 chunk).  Not for kind="nonneg" (needs global moments)."""
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((32, d)).astype(np.float32) * 4.0
+    if rank:
+        rng = np.random.default_rng(seed + rank)
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        noise = rng.standard_normal((m, d), dtype=np.float32)
+        yield s, (noise if kind == "iso" else centers[rng.integers(0, 32, m)] + noise)
+
+
 def make_shard_numpy(n, d, seed, kind="blobs", rank=0):
     """`numpy.random.default_rng(seed)` on the host, reproducible on any box.  blobs: 32
     centres ~ N(0, 16 I) from the stream `seed` (ONE set for the whole data set), unit noise, labels
     uniform; the rows of rank r come from the stream `seed + r` (rank 0 goes on with the stream that
     drew the centres).  iso: one isotropic Gaussian.  nonneg: clip(blobs, 0), scaled to [0, 255],
     standardised."""
-    rng = np.random.default_rng(seed)
-    centers = rng.standard_normal((32, d)).astype(np.float32) * 4.0
-    if rank:
-        rng = np.random.default_rng(seed + rank)
     X = np.empty((n, d), dtype=np.float32)
-    step = 100_000
-    for s in range(0, n, step):
-        m = min(step, n - s)
-        noise = rng.standard_normal((m, d), dtype=np.float32)
-        X[s:s + m] = noise if kind == "iso" else centers[rng.integers(0, 32, m)] + noise
+    for s, chunk in iter_shard_numpy(n, d, seed, kind, rank):
+        X[s:s + chunk.shape[0]] = chunk
     if kind == "nonneg":
         np.clip(X, 0, None, out=X)
         X *= 255.0 / float(X.max())
@@ -155,17 +161,20 @@ def make_shard_device(torch, n, d, seed, device, rank=0, kind="blobs"):
     if os.environ.get("DBGSOM_BENCH_DATA", "numpy") == "torch":
         return make_shard(torch, n, d, seed, device, rank, kind)
     X = torch.empty((n, d), dtype=torch.float32, device=device)
-    Xh = make_shard_numpy(n, d, seed, kind, rank)
-    step = 250_000
-    for s0 in range(0, n, step):
-        X[s0:s0 + step] = torch.from_numpy(Xh[s0:s0 + step]).to(device)
+    if kind == "nonneg":
+        Xh = make_shard_numpy(n, d, seed, kind, rank)
+        for s0 in range(0, n, 250_000):
+            X[s0:s0 + 250_000] = torch.from_numpy(Xh[s0:s0 + 250_000]).to(device)
+        return X
+    for s0, chunk in iter_shard_numpy(n, d, seed, kind, rank):   # (chunk by chunk: a C5 shard is 4 GB of float32)
+        X[s0:s0 + chunk.shape[0]] = torch.from_numpy(chunk).to(device)
     return X
 
 
 # ---------------------------------------------------------------------------------------------
 # CPU baseline (the oracle port of the reference path), rank 0 at N = 1 only
 # ---------------------------------------------------------------------------------------------
-def cpu_baseline(Xs, W, hop, sigma, gamma, n_full):
+def cpu_baseline(Xs, W, hop, sigma, gamma, n_full, budget_s=15.0):
     """The reference CPU path (oracle port: sklearn NearestNeighbors + NumPy) on a bounded row
     sample, extrapolated to the full N: t = (t_bmu + t_acc) * N / Ns + t_smooth, with the smoothing
     both ways SURVEY.md 8(d) asks for: (ii) matmul form -- the fair baseline behind `value` -- and
@@ -180,11 +189,11 @@ def cpu_baseline(Xs, W, hop, sigma, gamma, n_full):
     except ImportError:
         bmu, engine = o.bmu_blas, "NumPy dgemm expanded-L2"
     M, d = W.shape
-    # size the sample for ~15 s of CPU work: probe the BMU rate on 10k rows first
+    # size the sample for ~budget_s of CPU work: probe the BMU rate on 10k rows first
     tp = time.perf_counter()
     bmu(Xs[:10_000], W, 1)
     rate = 10_000 / (time.perf_counter() - tp)
-    ns = int(min(Xs.shape[0], max(20_000, rate * 15.0)))
+    ns = int(min(Xs.shape[0], max(20_000, rate * budget_s)))
     Xs = Xs[:ns]
     t0 = time.perf_counter()
     dist, win = bmu(Xs, W, 1)
@@ -257,9 +266,13 @@ def parity_gate(X, W0, hop, sigma, gamma, info, Wn_hip, xbytes):
     scale = float(np.median(dist_cpu ** 2)) if ns else 1.0
     d_err = float(np.max(np.abs(dist[:ns] ** 2 - dist_cpu ** 2) / (dist_cpu ** 2 + scale))) if ns else 0.0
     M = W0.shape[0]
-    Xh = X.float().cpu().numpy() if xbytes == 2 else X.cpu().numpy()
     kw = o.exp_similarity_gamma(dist, gamma)
-    S, K, a, E = o.accumulate_numpy(Xh, win, kw, dist, M)
+    S = K = a = E = None
+    for s0 in range(0, win.size, 250_000):   # (row chunks: a C5 shard is 4 GB of float32 on the host)
+        s1 = min(win.size, s0 + 250_000)
+        Xh = X[s0:s1].float().cpu().numpy() if xbytes == 2 else X[s0:s1].cpu().numpy()
+        part = o.accumulate_numpy(Xh, win[s0:s1], kw[s0:s1], dist[s0:s1], M)
+        S, K, a, E = part if S is None else (S + part[0], K + part[1], a + part[2], E + part[3])
     Wn = o.smooth_matmul(o.gaussian_neighborhood(hop, sigma), a, o.voronoi_centers(S, K, a, "compact"))
     scale = np.maximum(np.abs(Wn), 1e-12 * np.abs(Wn).max())
     w_err = float(np.nanmax(np.abs(Wn_hip - Wn) / scale))
@@ -685,6 +698,62 @@ def other_data_regime(h, torch, device, name):
     return out
 
 
+def workload_entry(h, torch, device, name, cpu_budget_s):
+    """One more BASELINE configuration in the same line (N = 1): the frozen-map step of workload `name` with the
+    stateless filtered search and with the all-pairs search, its rooflines, its CPU leg on a bounded row sample and
+    ITS OWN parity gate (winners of the sampled rows against the reference's engine, the new prototypes of the whole
+    epoch against the oracle's update on all rows)."""
+    n, d, rows, cols, seed, kind, cfg_name = WORKLOADS[name]
+    M = rows * cols
+    X = make_shard_device(torch, n, d, seed, device, 0, kind)
+    xbytes = 4
+    if name in BF16_WORKLOADS:
+        X = X.to(torch.bfloat16)
+        xbytes = 2
+    mom = torch.zeros(2 * d, dtype=torch.float64, device=device)
+    for s0 in range(0, n, 100_000):
+        blk = X[s0:s0 + 100_000].double()
+        mom[:d] += blk.sum(dim=0)
+        mom[d:] += (blk * blk).sum(dim=0)
+    gamma = float(1.0 / (mom[d:] / n - (mom[:d] / n) ** 2).sum().item())
+    sel = torch.from_numpy(np.random.default_rng(seed + 7).choice(n, M, replace=False)).to(device)
+    W0 = X[sel].double().cpu().numpy()
+    hop, sigma = lattice_hops(rows, cols), 0.2 * np.sqrt(M)
+    el, ph, info, counts, Wn = frozen_map_regime(h, "filtered", X, W0, hop, sigma, gamma, assignments=cpu_budget_s > 0)
+    e_el, e_ph, e_info, _, e_Wn = frozen_map_regime(h, "exact", X, W0, hop, sigma, gamma,
+                                                     steps=min(h.args.steps, 10), warmup=min(h.args.warmup, 2))
+    med, e_med = float(np.median(info["step_seconds"])), float(np.median(e_info["step_seconds"]))
+    roofs = rooflines(name, n, d, M, xbytes, ph, int(info.get("sweep_planes", 1)), counts, bool(info.get("refined")))
+    out = {"workload": cfg_name, "value": n / med, "unit": "samples/s/epoch", "ms_per_step": med * 1e3,
+           "floor": n / e_med, "floor_ms_per_step": e_med * 1e3,
+           "floor_roofline": exact_roofline(n, d, M, e_ph["bmu"]),
+           "roofline": max(roofs[:2], key=lambda r: r["kernel_ms"]) if len(roofs) >= 2 else roofs[0],
+           "rooflines": roofs, "phases_ms": ph,
+           "filter": {"sweep_planes": info.get("sweep_planes"), "refined": info.get("refined", False),
+                      "candidates_per_workgroup": info.get("candidates_per_workgroup")},
+           "prototypes_identical_to_all_pairs": bool(np.array_equal(e_Wn, Wn, equal_nan=True))}
+    if cpu_budget_s > 0:
+        Xs = X[:min(n, 200_000)].float().cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline(Xs, W0, hop, sigma, gamma, n, budget_s=cpu_budget_s)
+        out["gpu_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        out["parity"] = parity_gate(X, W0, hop, sigma, gamma, info, Wn, xbytes)
+    del X
+    torch.cuda.empty_cache()
+    return out
+
+
+def fit_regime(X_host, max_neurons):
+    """A whole `SomVQ.fit` (the reference's entry point, BaseSom.py:88-131) on the workload's samples handed over as
+    a host array: wall clock, epochs, the share spent outside the C ABI, bytes over PCIe (tools/bench_fit.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_fit import fit_profile
+
+    kw = dict(random_state=0, max_neurons=max_neurons, n_iter=120, spreading_factor=0.9, convergence_iter=1,
+              coarse_training_frac=0.7)
+    fit_profile(X_host[:4000], **dict(kw, n_iter=8))   # (library and allocator warm)
+    return fit_profile(X_host, **kw)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -704,6 +773,11 @@ def main():
                          "the exact and the hinted filtered search (0 disables)")
     ap.add_argument("--other-data", type=int, default=1,
                     help="N = 1, workload c4: also run the weakly clustered data sets c4iso and c2nn")
+    ap.add_argument("--other-workloads", type=int, default=1,
+                    help="N = 1, workload c4: also run BASELINE's c3, c2 and the c5 shard, each with its own "
+                         "rooflines, CPU leg on a bounded row sample and parity gate (`other_workloads`)")
+    ap.add_argument("--fit", type=int, default=1,
+                    help="N = 1, workload c4: also time a whole SomVQ.fit on the workload's samples (`fit`)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="upper bound of rows timed by the CPU baseline (0 disables it); the "
                          "actual sample is sized for ~15 s of CPU work")
@@ -883,6 +957,17 @@ def main():
             out["gpu_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["parity"] = parity_gate(X, W0, hop, sigma, gamma, results[args.algorithm][2],
                                         results[args.algorithm][4], xbytes)
+        if world == 1 and args.fit and args.workload == "c4" and not args.samples_per_gpu:
+            out["fit"] = fit_regime(X.float().cpu().numpy(), 1024)
+        if world == 1 and args.other_workloads and args.workload == "c4" and not args.samples_per_gpu:
+            del X
+            torch.cuda.empty_cache()
+            out["other_workloads"] = {name: workload_entry(h, torch, device, name, 4.0 if args.cpu_sample > 0 else 0.0)
+                                      for name in ("c3", "c2", "c5")}
+            bad = [k for k, v in out["other_workloads"].items() if v.get("parity") and not v["parity"]["ok"]]
+            if bad and out.get("parity"):
+                out["parity"]["other_workloads_failed"] = bad
+                out["parity"]["ok"] = False
         if out.get("other_data"):   # the same step on data without clusters: what the headline owes its data set
             iso = out["other_data"]["c4iso"]["auto"]
             out["value_isotropic"] = iso["value"]

@@ -304,7 +304,11 @@ struct dbgsom_ctx {
     double arm_seen[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};   // last result ever
     int arm_age[3][4] = {};   // updates of the map since the arm last ran
     // measured: wall clock (ms) of the blocking epoch call when the arm last ran WITHOUT anything riding along (a
-    // counting-only launch, re-seeding passes, the refinement's own measurements, results copied to the host);
+    // counting-only launch, the refinement's own measurements, results copied to the host).  The re-seeding passes
+    // of the pruning arm are NOT "riding along": `prune_retry` stays on for as long as the arm's cheap seeds leave
+    // workgroups with long lists, so they are what the arm costs on this data (round 3's advisor asked to drop such
+    // epochs: with the flag sticky no arm would ever be timed again -- tests/test_gpu_parity.py
+    // test_search_arms_that_have_been_timed_...); sweep arms do not look at the flag at all.
     // two arms that both have one are compared by it, the cost model only prices arms that have none
     double arm_ms[3][4] = {{NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}, {NAN, NAN, NAN, NAN}};
     double last_epoch_ms = NAN;     // of the epoch update_policy is looking at (NaN: not a clean measurement)
@@ -1635,7 +1639,7 @@ int dbgsom_ctx_epoch(dbgsom_ctx *c, const double *W_host, int64_t M, int round_f
             ++r.n[measuring];
         }
         c->last_frozen = (flags & DBGSOM_EPOCH_FROZEN) != 0;
-        c->last_epoch_ms = (c->last_filtered && !c->last_probed && !c->last_guarded && !c->last_retry && measuring < 0 && !W_new_host && !idx_host && !dist_host)
+        c->last_epoch_ms = (c->last_filtered && !c->last_probed && !c->last_guarded && measuring < 0 && !W_new_host && !idx_host && !dist_host)
                                ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()
                                : NAN;
         update_policy(c, c->tail.as<double>()[2 * M + 2], c->tail.as<double>()[2 * M + 3], c->tail.as<double>()[2 * M + 4],

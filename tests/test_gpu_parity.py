@@ -122,8 +122,12 @@ def test_golden_epochs(hip, o, name):
         assert np.array_equal(res.activations, g[f"e{e}_activations"])
         if f"e{e}_errors" in g:
             np.testing.assert_allclose(res.errors, g[f"e{e}_errors"], rtol=1e-9, atol=1e-6)
-        np.testing.assert_allclose(res.new_weights, g[f"e{e}_weights_out"], rtol=1e-7, atol=1e-9,
-                                   equal_nan=True)
+        # (float32 prototypes -- epoch 0 of a float32 fit: the reference returns distances rounded through float32,
+        #  and of 20 000 samples a few sit on a rounding boundary that BLAS order and chain order resolve
+        #  differently; their sample weights move by 1e-7 and the 4 start prototypes by 1.5e-8.  north_star: 1e-5)
+        f32w = W.dtype == np.float32
+        np.testing.assert_allclose(res.new_weights, g[f"e{e}_weights_out"], rtol=1e-6 if f32w else 1e-7,
+                                   atol=1e-7 if f32w else 1e-9, equal_nan=True)
         # against the oracle on the same inputs: tight
         oo = o.epoch(X, W, hop, float(g[f"e{e}_sigma"]), X.dtype.type(g[f"e{e}_total_variance"]),
                      "compact", "chain")
