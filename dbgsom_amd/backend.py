@@ -302,6 +302,7 @@ class HipBackend(HotPathBackend):
     # the new prototypes): 0 never, 1 whenever the collective can, 2 (default) on large maps
     shard_smooth = property(lambda self: self._get("shard_smooth"), lambda self, v: self._set("shard_smooth", int(v)))
     shard_epochs = property(lambda self: self._get("shard_epochs"))
+    defer_epochs = property(lambda self: self._get("defer_epochs"))
     planes_cached = property(lambda self: bool(self._get("planes_cached")))
     padded_features = property(lambda self: self._get("padded_features"))
 

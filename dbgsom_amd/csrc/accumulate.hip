@@ -12,6 +12,8 @@
 // bucketed by winner with a stable counting sort (per-workgroup LDS histograms + a column scan),
 // each neuron's list is cut into chunks of <= CH rows, one workgroup sums one chunk in list
 // order, and a second pass adds a neuron's chunk partials in chunk order.
+#include <type_traits>
+
 #include "common.h"
 
 namespace dbgsom {
@@ -352,83 +354,116 @@ __global__ __launch_bounds__(AT) void segsum_kernel(
 // ---- 5b. the same chunk, with the distances of the rows that do not have one yet ----------------------
 // The refinement of the filtered search (filter.hip 2d) knows the winner of a sample whose candidates it
 // could narrow down to ONE without ever touching the sample's float rows; its distance is the float64 chain
-// against that one prototype -- against THIS chunk's prototype.  Such rows arrive with dist == -1: the
-// chunk's rows are brought into LDS in sub-blocks of SR whole rows (LDS-DMA, two buffers), one lane per row
-// runs the chain acc = fma(w_k, x_k, acc), k ascending (the arithmetic of every exact BMU kernel: same
-// bits), then all threads form the weighted sums from the same LDS image -- the float rows are streamed
-// ONCE for the distance and the sums (pair kernel + segsum: twice).  Sums, their order of additions and
-// the scalar partials are those of segsum_kernel bit for bit.
-typedef __attribute__((address_space(3))) void *acc_lds_ptr_t;
-typedef const __attribute__((address_space(1))) void *acc_gbl_ptr_t;
-__device__ __forceinline__ void acc_dma16(const void *src, void *lds_dst) {
-    __builtin_amdgcn_global_load_lds((acc_gbl_ptr_t)src, (acc_lds_ptr_t)lds_dst, 16, 0, 0);
-}
-constexpr int SR = 16;   // rows per sub-block (lanes of the chain)
-constexpr int SD_QG = 4; // column groups a thread keeps across the sub-blocks of a chunk (rows of <= 4 AT groups)
+// against that one prototype -- against THIS chunk's prototype.  Such rows arrive with dist == -1.  The float
+// rows are streamed ONCE for the distance and the sums (pair kernel + segsum_kernel: twice):
+//
+//  * a chunk is walked in slices of SR = 16 rows; every thread loads its column group (16 bytes) of the
+//    slice's rows into REGISTERS -- as in segsum_kernel, 16 loads in flight per thread -- and keeps them;
+//  * the chain acc = fma(w_k, x_k, acc), k ascending, runs on the matrix cores of ONE wavefront:
+//    v_mfma_f64_4x4x4_4b (four 4x4x4 blocks, 16 B-columns per instruction = the slice's 16 rows against the
+//    chunk's prototype in every A row) is that chain bit for bit, like the 16x16x4 form of the exact kernels,
+//    at a quarter of its pipe time (tools/probe_mfma_f64_4x4.hip: 17.6 cycles per instruction, 43.6 cycles from
+//    one dependent instruction to the next -- 26 without the loop branch, 51 with B read from LDS and widened in
+//    front of it, tools/probe_mfma_chain.hip).  The operands reach it through LDS in ranges of 64 column groups:
+//    the threads of range r + 1 write their registers (raw 16-byte pieces, row pitch 65 pieces: no bank
+//    conflicts on either side) while the chain walks range r; one barrier per range.  (Ranges of values already
+//    widened to float64 by their owners were measured: twice the LDS bytes and a second conversion of every
+//    value -- slower, C4 1.27 against 1.12 ms, the C5 shard 2.33 against 1.38.);
+//  * the distances and the sample kernel follow, then all threads form the weighted sums FROM THEIR REGISTERS
+//    in list order.  Sums, their order of additions and the scalar partials are those of segsum_kernel bit
+//    for bit (the two search forms must leave bit-identical prototypes).
+// A slice none of whose rows needs a distance skips the chain altogether.
+#ifndef CHAIN_STAMPS
+#define CHAIN_STAMPS 0   // experiment builds (tools/build_variant.sh): 1 = per-phase s_memtime sums of a workgroup, left in
+#endif                   // `dist` of the chunk's first rows as -(1e12 + phase 1e10 + cycles) (tools/chain_stamps.py)
+#if CHAIN_STAMPS
+#define CSTAMP(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); if (tid == 0) { st_acc[k] += now_ - st_last; } st_last = now_; } while (0)
+#else
+#define CSTAMP(k)
+#endif
+#ifndef CHAIN_CB
+#define CHAIN_CB 4        // k-steps per batch of the chain's operand ring
+#endif
+#ifndef CHAIN_CW
+#define CHAIN_CW ((c >> 8) & 3u)
+#endif
+#ifndef CHAIN_PAD
+#define CHAIN_PAD 0        // experiment builds: bytes of LDS a workgroup asks for on top (fewer workgroups per CU)
+#endif
+#ifndef CHAIN_OCC
+#define CHAIN_OCC 3       // wavefronts per SIMD the one-group kernel is compiled for
+#endif
+constexpr int SR = 16;     // rows per slice = B-columns of one matrix instruction
+constexpr int SRG = 64;    // column groups (16-byte pieces) per range
+constexpr int SRP = (SRG + 1) * 16;   // bytes per row of a range buffer (one piece of padding)
 
-struct SegDistLds {   // byte offsets inside the one dynamic LDS object
-    int buf_bytes, o_w, o_rows, o_kw, o_dist, o_red, o_info, total;
+struct ChainLds {   // byte offsets inside the one dynamic LDS object (see refine.h: one object, no alias waits)
+    int o_w, o_rows, o_kw, o_dist, o_xx, o_info, total;   // (the two range buffers sit at 0; `red` reuses them)
 };
-static SegDistLds segdist_lds(int64_t d, size_t es, int vec) {
-    SegDistLds l;
-    l.buf_bytes = (int)(((size_t)SR * d * es + 1023) / 1024 * 1024);
-    l.o_w = 2 * l.buf_bytes;
+static ChainLds chain_lds(int64_t d) {
+    ChainLds l;
+    l.o_w = 2 * SR * SRP;
     l.o_rows = l.o_w + (int)d * 8;
     l.o_kw = l.o_rows + CH * 4;
     l.o_dist = l.o_kw + CH * 8;
-    l.o_red = l.o_dist + CH * 8;
-    l.o_info = l.o_red + AT * vec * 8;
-    l.total = l.o_info + 16;
+    l.o_xx = l.o_dist + CH * 8;
+    l.o_info = l.o_xx + CH * 8;
+    l.total = l.o_info + 32;
     return l;
 }
 
+typedef unsigned raw4_t __attribute__((ext_vector_type(4)));
 template <typename XT, int VEC>
-__device__ __forceinline__ void lds_vec(const char *src, double (&v)[VEC]) {
+__device__ __forceinline__ void raw_vec(const raw4_t r, double (&v)[VEC]) {
     if constexpr (sizeof(XT) == 4 && VEC == 4) {
-        typedef float f4_t __attribute__((ext_vector_type(4)));
-        const f4_t t4 = *reinterpret_cast<const f4_t *>(src);
-        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (double)__uint_as_float(r[e]);
     } else if constexpr (sizeof(XT) == 8 && VEC == 2) {
-        typedef double d2v_t __attribute__((ext_vector_type(2)));
-        const d2v_t t2 = *reinterpret_cast<const d2v_t *>(src);
-        v[0] = t2.x; v[1] = t2.y;
+        v[0] = __hiloint2double((int)r[1], (int)r[0]);
+        v[1] = __hiloint2double((int)r[3], (int)r[2]);
     } else {
         static_assert(sizeof(XT) == 2 && VEC == 8, "unsupported vector width");
-        typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-        const u4_t a = *reinterpret_cast<const u4_t *>(src);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[2 * e] = (double)__uint_as_float(a[e] << 16);
-            v[2 * e + 1] = (double)__uint_as_float(a[e] & 0xffff0000u);
+            v[2 * e] = (double)__uint_as_float(r[e] << 16);
+            v[2 * e + 1] = (double)__uint_as_float(r[e] & 0xffff0000u);
         }
     }
 }
 
-template <typename XT, int VEC>
-__global__ __launch_bounds__(AT) void segsum_dist_kernel(
+// G = column groups per thread (rows of more than AT groups: q = tid + g AT)
+template <typename XT, int VEC, int G>
+__global__ __launch_bounds__(AT, G == 1 ? CHAIN_OCC : 2) void segsum_chain_kernel(
     const XT *__restrict__ X, int d, int64_t ldx, const int32_t *__restrict__ order, double gamma,
     double *__restrict__ dist, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ count,
     const uint32_t *__restrict__ chunk_pre, int M, double *__restrict__ slab, const double *__restrict__ W,
-    const double *__restrict__ ww, const double *__restrict__ xx, int round_f32, SegDistLds L) {
-    extern __shared__ __attribute__((aligned(16))) char dyn[];   // ONE LDS object (see refine.h)
+    const double *__restrict__ ww, const double *__restrict__ xx, int round_f32, ChainLds L) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
     double *w_s = reinterpret_cast<double *>(dyn + L.o_w);
     int32_t *rows_s = reinterpret_cast<int32_t *>(dyn + L.o_rows);
     double *kw_s = reinterpret_cast<double *>(dyn + L.o_kw), *dist_s = reinterpret_cast<double *>(dyn + L.o_dist);
-    double *red = reinterpret_cast<double *>(dyn + L.o_red);
+    double *xx_s = reinterpret_cast<double *>(dyn + L.o_xx);
+    double *red = reinterpret_cast<double *>(dyn);
     uint32_t *info = reinterpret_cast<uint32_t *>(dyn + L.o_info);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t c = blockIdx.x;
     if (c >= chunk_pre[M]) return;  // uniform per workgroup
-    if (tid == 0) {
-        int lo = 0, hi = M;  // last j with chunk_pre[j] <= c
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (chunk_pre[mid] <= c) lo = mid; else hi = mid;
+#if CHAIN_STAMPS
+    uint64_t st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
+    {   // the chunk's neuron: the one j with chunk_pre[j] <= c < chunk_pre[j + 1] -- every thread looks at its share of
+        // the table at once (one round trip instead of the ten of a binary search by one thread)
+        const int per = (M + AT - 1) / AT;
+        for (int u = 0; u < per; ++u) {
+            const int jj = tid * per + u;
+            if (jj < M && chunk_pre[jj] <= c && c < chunk_pre[jj + 1]) {
+                const uint32_t begin = seg_start[jj] + (c - chunk_pre[jj]) * CH;
+                const uint32_t end = min(begin + (uint32_t)CH, seg_start[jj] + count[jj]);
+                info[0] = begin; info[1] = end - begin; info[2] = (uint32_t)jj;
+            }
         }
-        const uint32_t begin = seg_start[lo] + (c - chunk_pre[lo]) * CH;
-        const uint32_t end = min(begin + (uint32_t)CH, seg_start[lo] + count[lo]);
-        info[0] = begin; info[1] = end - begin; info[2] = (uint32_t)lo;
+        if (tid == 0) info[3] = 0u;
     }
     __syncthreads();
     const uint32_t begin = info[0];
@@ -436,143 +471,188 @@ __global__ __launch_bounds__(AT) void segsum_dist_kernel(
     if (tid < n) {
         const int32_t r = order[begin + tid];
         rows_s[tid] = r;
-        dist_s[tid] = dist[r];   // (-1: to be computed here)
+        const double dd = dist[r];   // (-1: to be computed here)
+        dist_s[tid] = dd;
+        xx_s[tid] = xx[r];
+        // the sample kernel of BaseSom._calculate_exp_similarity (BaseSom.py:533-538), the arithmetic of
+        // exp_similarity_kernel (bmu.hip) and of segsum_kernel
+        kw_s[tid] = 1.0 - sqrt(1.0 - exp(-gamma * (dd * dd)));
+        if (dd == -1.0) atomicOr(&info[3], 1u << (tid / SR));   // slices with a row that needs its distance
     }
     for (int k = tid; k < d; k += AT) w_s[k] = W[(size_t)j * d + k];
     const double ww_j = ww[j];
     __syncthreads();
-    constexpr int ES = (int)sizeof(XT);
-    const int rowbytes = d * ES;
-    const int ninstr = L.buf_bytes / 1024;
-    // sub-block s into buffer s & 1: instruction i covers LDS bytes [1024 i, +1024) = 16-byte pieces of whole rows
-    auto issue = [&](int sb) {
-        char *buf = dyn + (sb & 1) * L.buf_bytes;
-        const int nrow = min(SR, n - sb * SR);
-        for (int i = wave; i < ninstr; i += AT / 64) {
-            const int a = i * 1024 + lane * 16;
-            int row = a / rowbytes;
-            const int off = a - row * rowbytes;
-            row = row < nrow ? row : nrow - 1;   // (behind the sub-block's rows: any valid address, never read)
-            acc_dma16(reinterpret_cast<const char *>(X + (int64_t)rows_s[sb * SR + row] * ldx) + off, buf + i * 1024);
-        }
-    };
-    const int nsub = (n + SR - 1) / SR;
-    const int Q = d / VEC;  // column groups (VEC divides d by construction)
+    const uint32_t need_mask = info[3];
+    const int Q = d / VEC;                       // column groups (VEC divides d by construction)
     const bool wide = Q >= AT;
-    const int RL = wide ? 1 : AT / Q;  // row lanes working side by side on the same column group (segsum_kernel)
+    const int RL = wide ? 1 : AT / Q;            // row lanes side by side on the same column group (segsum_kernel)
     const int rl = wide ? 0 : tid / Q, q0 = wide ? tid : tid - rl * Q;
-    // (narrow rows: acc[0] = this thread's column group for its row lane; wide rows: up to SD_QG column groups
-    //  q = tid + g AT per thread, kept in registers across the sub-blocks -- the launcher checks Q <= SD_QG AT)
-    double acc[SD_QG][VEC];
+    const bool active = wide || rl < RL;
+    const int NR = (Q + SRG - 1) / SRG;          // ranges of 64 column groups
+    const int cw = (int)(CHAIN_CW);             // the chain's wavefront: spread over the SIMDs (chunks resident on one CU
+                                                 // share c mod 256 -- XCD, then CU, round robin -- so the bits above decide)
+    const int lr = lane & 15, lq = lane >> 4;    // B operand: column (row of the slice) lr, k = lq
+    double acc[G][VEC];
 #pragma unroll
-    for (int g = 0; g < SD_QG; ++g)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[g][e] = 0.0;
     double *out = slab + (size_t)c * (d + 2);
-    issue(0);
-    for (int sb = 0; sb < nsub; ++sb) {
+    int my_range[G], my_off[G];   // where this thread's column groups go in the range buffers
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int q = q0 + g * AT;
+        my_range[g] = (active && q < Q) ? q / SRG : -1;
+        my_off[g] = (q % SRG) * 16;
+    }
+    CSTAMP(0);
+
+    for (int s0 = 0; s0 < n; s0 += SR) {
+        const int nrow = min(SR, n - s0);
+        // ---- the slice's rows into registers (a thread's row lane: rows p = rl, rl + RL, ... of the chunk)
+        raw4_t raw[SR][G];
+        // bit i: row s0 + i is one of this thread's (its row lane: rows p = rl, rl + RL, ... of the chunk)
+        uint32_t mine = 0u;
+        if (active) {
+            if (RL == 1) mine = 0xffffu;
+            else for (int i = (rl - s0 % RL + RL) % RL; i < SR; i += RL) mine |= 1u << i;
+            mine &= (1u << nrow) - 1u;
+        }
+#pragma unroll
+        for (int i = 0; i < SR; ++i) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                raw[i][g] = raw4_t{0u, 0u, 0u, 0u};
+                if (((mine >> i) & 1u) && my_range[g] >= 0)
+                    raw[i][g] = *reinterpret_cast<const raw4_t *>(X + (int64_t)rows_s[s0 + i] * ldx + (int64_t)(q0 + g * AT) * VEC);
+            }
+        }
+        CSTAMP(1);
+#if CHAIN_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // sub-block sb has landed; buffer (sb + 1) & 1 has been summed
-        if (sb + 1 < nsub) issue(sb + 1);
-        const char *buf = dyn + (sb & 1) * L.buf_bytes;
-        const int nrow = min(SR, n - sb * SR);
-        if (tid < SR) {   // ---- the chains: lane = row
-            const int p = sb * SR + tid;
-            const bool need = tid < nrow && dist_s[p] == -1.0;
-            if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
-                const char *xr = buf + (tid < nrow ? tid : 0) * rowbytes;
-                double a = 0.0;
-                // 16 features per block, the NEXT block's LDS reads in flight under this block's 16 dependent
-                // fmas (sched_barriers: left alone the compiler reuses one register quad for every read and
-                // waits for each -- 24 exposed LDS round trips per block, 7 x the time of the chain itself)
-                // (raw 16-byte pieces are kept as they come and widened in the fma phase: the wait for a block's
-                //  reads then sits in front of ITS fmas, one block later)
-                typedef unsigned raw4_t __attribute__((ext_vector_type(4)));
-                constexpr int XR = ES;            // 16-byte pieces of 16 features of the row: 4 (f32), 8 (f64), 2 (bf16)
-                struct Blk { raw4_t x[XR]; raw4_t w[8]; };
-                auto load_block = [&](int k, Blk &b) {
+        CSTAMP(2);
+#endif
+        if ((need_mask >> (s0 / SR)) & 1u) {   // (uniform)
+            // ---- the chain: ranges of 64 column groups through two LDS buffers
+            // (rows behind the slice's end: zeros, written by row lane 0 -- never garbage in a B column)
+            const uint32_t wmask = mine | ((active && rl == 0) ? (0xffffu & ~((1u << nrow) - 1u)) : 0u);
+            auto write_range = [&](int r) {
 #pragma unroll
-                    for (int u = 0; u < XR; ++u) b.x[u] = *reinterpret_cast<const raw4_t *>(xr + k * ES + 16 * u);
+                for (int g = 0; g < G; ++g) {
+                    if (my_range[g] == r) {
+                        char *dst = dyn + (r & 1) * (SR * SRP) + my_off[g];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) b.w[u] = *reinterpret_cast<const raw4_t *>(reinterpret_cast<const char *>(w_s + k) + 16 * u);
-                };
-                auto chain_block = [&](const Blk &b) {
-                    // (the prototype is the first factor, as the A operand of the matrix instruction)
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const raw4_t wq = b.w[u >> 1];
-                        const double wv = __hiloint2double((int)wq[2 * (u & 1) + 1], (int)wq[2 * (u & 1)]);
-                        double xv;
-                        if constexpr (ES == 4) {
-                            xv = (double)__uint_as_float(b.x[u >> 2][u & 3]);
-                        } else if constexpr (ES == 8) {
-                            const raw4_t xq = b.x[u >> 1];
-                            xv = __hiloint2double((int)xq[2 * (u & 1) + 1], (int)xq[2 * (u & 1)]);
-                        } else {
-                            const unsigned wd = b.x[u >> 3][(u & 7) >> 1];
-                            xv = (double)__uint_as_float((u & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                        for (int i = 0; i < SR; ++i) {
+                            if ((wmask >> i) & 1u) *reinterpret_cast<raw4_t *>(dst + i * SRP) = raw[i][g];
                         }
-                        a = fma(wv, xv, a);
                     }
-                };
-                Blk ba, bb;
-                load_block(0, ba);
-                for (int k = 0; k < d; k += 32) {   // (d % 16 == 0: the engine's padded rows)
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (k + 16 < d) load_block(k + 16, bb);
-                    __builtin_amdgcn_sched_barrier(0);
-                    chain_block(ba);
-                    if (k + 16 >= d) break;
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (k + 32 < d) load_block(k + 32, ba);
-                    __builtin_amdgcn_sched_barrier(0);
-                    chain_block(bb);
                 }
-                if (need) {
-                    const int32_t r = rows_s[p];
-                    double rv = (xx[r] + (-2.0 * a)) + ww_j;
+            };
+            double a4 = 0.0;   // the chain's accumulator: lanes 0 .. 15 = rows of the slice
+            write_range(0);
+            __syncthreads();
+            CSTAMP(3);
+            for (int r = 0; r < NR; ++r) {
+                if (r + 1 < NR) write_range(r + 1);
+                if (wave == cw) {
+                    const char *buf = dyn + (r & 1) * (SR * SRP) + lr * SRP + lq * (int)sizeof(XT);   // B: row lr, feature k0 + lq
+                    const int nstep = min(SRG, Q - r * SRG) * VEC / 4;                 // k-steps of 4 features in this range
+                    const double *wk = w_s + (size_t)r * SRG * VEC + lq;               // A: w[k0 + lq] in every A row
+                    auto ld_a = [&](int st) { return wk[4 * st]; };
+                    // (B stays as it was read until its matrix instruction: widened at the point of the read, the
+                    //  conversion -- and with it the wait for the NEXT batch's reads -- would sit in front of this
+                    //  batch's instructions)
+                    typedef typename std::conditional<sizeof(XT) == 8, double, unsigned>::type braw_t;
+                    auto ld_b = [&](int st) -> braw_t {
+                        if constexpr (sizeof(XT) == 4) return *reinterpret_cast<const unsigned *>(buf + st * 16);
+                        else if constexpr (sizeof(XT) == 8) return *reinterpret_cast<const double *>(buf + st * 32);
+                        else return (unsigned)*reinterpret_cast<const unsigned short *>(buf + st * 8);
+                    };
+                    auto wid = [&](braw_t v) -> double {
+                        if constexpr (sizeof(XT) == 4) return (double)__uint_as_float(v);
+                        else if constexpr (sizeof(XT) == 8) return v;
+                        else return (double)__uint_as_float(v << 16);
+                    };
+                    // double batches of 2 CB steps: the next batch's LDS reads are in flight under this batch's dependent
+                    // matrix instructions.  Every read of the loop is unconditional (the last one runs a batch past the
+                    // range: still inside this workgroup's LDS, never used): with reads under a condition the compiler's
+                    // wait counts merge the two paths and every batch waits for the reads just issued (71 cycles per
+                    // step instead of ~55)
+                    constexpr int CB = CHAIN_CB;
+                    const int npair = nstep / (2 * CB);
+                    if (npair) {
+                        double a0[CB], a1[CB];
+                        braw_t b0[CB], b1[CB];
+#pragma unroll
+                        for (int u = 0; u < CB; ++u) { a0[u] = ld_a(u); b0[u] = ld_b(u); }
+                        for (int it = 0, st = 0; it < npair; ++it, st += 2 * CB) {
+#pragma unroll
+                            for (int u = 0; u < CB; ++u) { a1[u] = ld_a(st + CB + u); b1[u] = ld_b(st + CB + u); }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < CB; ++u) a4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[u], wid(b0[u]), a4, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < CB; ++u) { a0[u] = ld_a(st + 2 * CB + u); b0[u] = ld_b(st + 2 * CB + u); }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < CB; ++u) a4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[u], wid(b1[u]), a4, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    for (int st = npair * 2 * CB; st < nstep; ++st)
+                        a4 = __builtin_amdgcn_mfma_f64_4x4x4f64(ld_a(st), wid(ld_b(st)), a4, 0, 0, 0);
+                    CSTAMP(8);   // (the chain wave's own view: its matrix loop ...)
+                }
+                __syncthreads();
+                if (wave == cw) { CSTAMP(9); }   // (... and its wait at the range's barrier, writes of the next range included)
+            }
+            CSTAMP(4);
+            if (wave == cw && lane < nrow) {
+                const int p = s0 + lane;
+                if (dist_s[p] == -1.0) {
+                    double rv = (xx_s[p] + (-2.0 * a4)) + ww_j;
                     if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
                     double dv = sqrt(rv);
                     if (round_f32) dv = (double)(float)dv;
                     dist_s[p] = dv;
-                    dist[r] = dv;
+                    dist[rows_s[p]] = dv;
+                    kw_s[p] = 1.0 - sqrt(1.0 - exp(-gamma * (dv * dv)));
                 }
             }
-            if (tid < nrow) {
-                const double dd = dist_s[p];
-                // the sample kernel of BaseSom._calculate_exp_similarity (BaseSom.py:533-538), the arithmetic
-                // of exp_similarity_kernel (bmu.hip) and of segsum_kernel
-                kw_s[p] = 1.0 - sqrt(1.0 - exp(-gamma * (dd * dd)));
-            }
+            __syncthreads();
+            CSTAMP(5);
         }
-        __syncthreads();
-        // ---- the weighted sums of this sub-block's rows, in list order (segsum_kernel's order)
-        if (wide) {
+        // ---- the weighted sums of the slice's rows, in list order (segsum_kernel's order), from the registers
+        if (mine) {
 #pragma unroll
-            for (int g = 0; g < SD_QG; ++g) {
-                const int q = tid + g * AT;
-                if (q < Q)
-                    for (int t = 0; t < nrow; ++t) {
-                        const double w = kw_s[sb * SR + t];
+            for (int i = 0; i < SR; ++i) {
+                if ((mine >> i) & 1u) {
+                    const double w = kw_s[s0 + i];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
                         double v[VEC];
-                        lds_vec<XT, VEC>(buf + t * rowbytes + q * VEC * ES, v);
+                        // (laundered: the compiler must not keep the values widened for the range buffers alive until
+                        //  here -- 16 rows of them are 128 registers -- but widen the raw pieces once more)
+                        unsigned r0 = raw[i][g][0], r1 = raw[i][g][1], r2 = raw[i][g][2], r3 = raw[i][g][3];
+                        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                        raw_vec<XT, VEC>(raw4_t{r0, r1, r2, r3}, v);
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) acc[g][e] += w * v[e];
                     }
-            }
-        } else if (rl < RL) {
-            // (row lane rl takes the chunk's rows p = rl, rl + RL, ...)
-            int t = (rl - (sb * SR) % RL + RL) % RL;
-            for (; t < nrow; t += RL) {
-                const double w = kw_s[sb * SR + t];
-                double v[VEC];
-                lds_vec<XT, VEC>(buf + t * rowbytes + q0 * VEC * ES, v);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[0][e] += w * v[e];
+                }
             }
         }
+        CSTAMP(6);
     }
     __syncthreads();
+#if CHAIN_STAMPS
+    CSTAMP(7);
+    if (tid == 0 && n >= 11) {
+        for (int k = 0; k < 10; ++k) dist[rows_s[k]] = -(1e12 + 1e10 * k + (double)st_acc[k]);
+        dist[rows_s[10]] = -(1e12 + 1e10 * 10 + (double)n);
+    }
+#endif
     if (tid == AT - 1) {  // the scalar partials, in list order
         double sk = 0.0, se = 0.0;
         for (int p = 0; p < n; ++p) { sk += kw_s[p]; se += dist_s[p]; }
@@ -581,7 +661,7 @@ __global__ __launch_bounds__(AT) void segsum_dist_kernel(
     }
     if (wide) {
 #pragma unroll
-        for (int g = 0; g < SD_QG; ++g) {
+        for (int g = 0; g < G; ++g) {
             const int q = tid + g * AT;
             if (q < Q)
 #pragma unroll
@@ -715,8 +795,8 @@ int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order,
 bool accumulate_can_fill_distances(int x_dtype, int64_t d) {
     if (d % 16 != 0) return false;
     const int vec = x_dtype == DBGSOM_F32 ? 4 : (x_dtype == DBGSOM_F64 ? 2 : 8);
-    if (d / vec > (int64_t)SD_QG * AT) return false;
-    return segdist_lds(d, dtype_size(x_dtype), vec).total <= 160 * 1024;
+    if (d / vec > 2 * (int64_t)AT) return false;              // (two column groups per thread at most)
+    return chain_lds(d).total <= 96 * 1024 && (size_t)AT * vec * 8 <= (size_t)2 * SR * SRP;   // (`red` reuses the range buffers)
 }
 
 static int accumulate_impl(const void *X, int x_dtype, int64_t N, int64_t d, int64_t ldx,
@@ -761,23 +841,23 @@ static int accumulate_impl(const void *X, int x_dtype, int64_t N, int64_t d, int
         // rows with dist == -1 get their distance (to their winner: this chunk's prototype) on the way
         DBGSOM_REQUIRE(!kw && al16 && accumulate_can_fill_distances(x_dtype, d) && fill->W && fill->ww && fill->xx,
                        "distances cannot be filled in for this shape");
-        const int vec = x_dtype == DBGSOM_F32 ? 4 : (x_dtype == DBGSOM_F64 ? 2 : 8);
-        const SegDistLds L = segdist_lds(d, xe, vec);
-#define DBGSOM_SEGDIST(XT, V)                                                                             \
+        const ChainLds L = chain_lds(d);
+        const bool two = d / (x_dtype == DBGSOM_F32 ? 4 : (x_dtype == DBGSOM_F64 ? 2 : 8)) > AT;
+#define DBGSOM_SEGDIST(XT, V, G_)                                                                         \
     do {                                                                                                  \
         static int attr_set = 0;                                                                          \
         if (attr_set < L.total) {                                                                         \
-            DBGSOM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&segsum_dist_kernel<XT, V>), \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set = 160 * 1024;                                                                        \
+            DBGSOM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&segsum_chain_kernel<XT, V, G_>), \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024 + CHAIN_PAD)); \
+            attr_set = 96 * 1024;                                                                         \
         }                                                                                                 \
-        hipLaunchKernelGGL((segsum_dist_kernel<XT, V>), grid, block, (size_t)L.total, s, (const XT *)X, di, ldx, \
+        hipLaunchKernelGGL((segsum_chain_kernel<XT, V, G_>), grid, block, (size_t)L.total + CHAIN_PAD, s, (const XT *)X, di, ldx, \
                            w.order, gamma, const_cast<double *>(dist), w.seg_start, w.count, w.chunk_pre, Mi, \
                            w.slab, fill->W, fill->ww, fill->xx, fill->round_f32, L);                      \
     } while (0)
-        if (x_dtype == DBGSOM_F32) DBGSOM_SEGDIST(float, 4);
-        else if (x_dtype == DBGSOM_F64) DBGSOM_SEGDIST(double, 2);
-        else DBGSOM_SEGDIST(bf16_t, 8);
+        if (x_dtype == DBGSOM_F32) { if (two) DBGSOM_SEGDIST(float, 4, 2); else DBGSOM_SEGDIST(float, 4, 1); }
+        else if (x_dtype == DBGSOM_F64) { if (two) DBGSOM_SEGDIST(double, 2, 2); else DBGSOM_SEGDIST(double, 2, 1); }
+        else { if (two) DBGSOM_SEGDIST(bf16_t, 8, 2); else DBGSOM_SEGDIST(bf16_t, 8, 1); }
 #undef DBGSOM_SEGDIST
     } else if (x_dtype == DBGSOM_F32) {
         if (al16 && d % 4 == 0) DBGSOM_SEGSUM(float, 4); else DBGSOM_SEGSUM(float, 1);

@@ -253,6 +253,7 @@ struct dbgsom_ctx {
     int defer = 0;                  // with the refinement: distances of decided samples inside the sums kernel
                                     // (experimental, off: one chain wavefront per CU cannot keep up -- NOTES.md)
     bool last_deferred = false;
+    int64_t defer_epochs = 0;       // epochs whose sums kernel also evaluated the distances the refinement left open
     int last_round_f32 = 0;
     int64_t rf_M = -1;
     int rf_measuring = -1;          // the form the running call is timing (-1: none)
@@ -974,6 +975,7 @@ int accumulate_and_reduce(dbgsom_ctx *c, const int64_t *idx, const double *kw, d
         fill.round_f32 = c->last_round_f32;
         TRY(launch_accumulate_epoch(s.X, s.dtype, s.N, s.dp, s.dp, idx, gamma, dist, M, c->sums.as<double>(), status,
                                     c->acc_ws.p, c->acc_ws.cap, c->stream, c->last_deferred ? &fill : nullptr));
+        if (c->last_deferred) ++c->defer_epochs;
         c->last_deferred = false;
     }
     c->sumsM = M;
@@ -1227,6 +1229,7 @@ int dbgsom_ctx_get_option(dbgsom_ctx *c, const char *name, int64_t *v) {
     else if (!strcmp(name, "defer")) *v = c->defer;
     else if (!strcmp(name, "shard_smooth")) *v = c->shard_smooth;
     else if (!strcmp(name, "shard_epochs")) *v = c->shard_epochs;
+    else if (!strcmp(name, "defer_epochs")) *v = c->defer_epochs;
     else if (!strcmp(name, "guarded_calls")) *v = c->guarded_calls;
     else if (!strcmp(name, "collective_rank")) *v = c->coll_rank;
     else if (!strcmp(name, "collective_ranks")) *v = c->coll_nranks;

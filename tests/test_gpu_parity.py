@@ -1345,6 +1345,53 @@ def test_refinement_at_the_edges_of_its_shapes(N, d, M, kind):
     ex.release()
 
 
+@pytest.mark.parametrize("dt,d,M", [("f32", 784, 300), ("f32", 256, 200), ("f32", 1040, 260), ("f32", 2048, 300),
+                                    ("bf16", 2048, 400), ("bf16", 512, 300), ("bf16", 4096, 200), ("f64", 320, 300),
+                                    ("f64", 784, 260), ("f32", 48, 200)])
+def test_distances_of_decided_samples_inside_the_sums_kernel(o, dt, d, M):
+    """`defer`: a sample the refinement narrows down to ONE candidate has its winner without its float row ever
+    being read; its distance is the chain against that prototype, evaluated by the epoch's sums kernel
+    (accumulate.hip: segsum_chain_kernel -- rows in registers, the chain on v_mfma_f64_4x4x4 through LDS ranges)
+    on the one pass it makes over the rows anyway.  Winners, distances AND the new prototypes are the all-pairs
+    search's bit for bit, for three storage types, rows of one and two column groups per thread, narrow rows with
+    several row lanes (d = 256: the sums' order of additions must be segsum_kernel's), chunks with and without rows
+    that need a distance, duplicated prototypes (undecided samples go through the pair kernel), ragged N."""
+    import torch
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(d + M)
+    N = 21_003
+    X, _ = gi.blobs_f32(N, d, d, n_centers=12)
+    if dt == "f64":
+        X = X.astype(np.float64) * 1.0000001
+    storage = "bf16" if dt == "bf16" else None
+    W = X[rng.choice(N, M, replace=False)].astype(np.float64)
+    W[7] = W[3]
+    W[50:54] = W[49]
+    hop = np.abs(np.subtract.outer(np.arange(M), np.arange(M))).astype(np.float64)
+    ex = HipBackend(algorithm="exact").load(X, storage=storage)
+    fi = HipBackend(algorithm="filtered").load(X, storage=storage)
+    fi.refine, fi.defer, fi.sweep_planes = 1, 1, 4
+    for e in range(3):
+        re_ = ex.epoch(W, hop, 1.5, 1e-3, "compact" if e else "aligned", True)
+        rf = fi.epoch(W, hop, 1.5, 1e-3, "compact" if e else "aligned", True)
+        assert fi.filter_log[-1][0] == "filtered" and fi.refined
+        assert np.array_equal(rf.winners, re_.winners), e
+        assert np.array_equal(rf.distances, re_.distances), e
+        assert np.array_equal(rf.new_weights, re_.new_weights, equal_nan=True), e
+        assert np.array_equal(rf.errors, re_.errors)
+        assert np.array_equal(rf.change_total, re_.change_total, equal_nan=True)   # (aligned layout: NaN rows of dead neurons)
+        if e == 0:
+            Xr = torch.from_numpy(X).to(torch.bfloat16).float().numpy() if dt == "bf16" else X
+            pick = rng.choice(N, 1000, replace=False)
+            rd, ri = o.bmu_chain(Xr[pick], W, 1)
+            assert np.array_equal(rf.winners[pick], ri) and np.array_equal(rf.distances[pick], rd)
+        W = np.nan_to_num(re_.new_weights)
+        fi.algorithm = "filtered_hint"
+    assert fi.defer_epochs == 3, fi.defer_epochs
+    ex.release(); fi.release()
+
+
 def test_refinement_with_non_finite_rows_and_extreme_scales():
     """A prototype row with a NaN or an infinity (dead neurons of the aligned layout) has no residual
     norm: the bound is void and every candidate is kept (overflow path); sample rows spanning dozens of
