@@ -209,6 +209,39 @@ class BaseSom(BaseEstimator):
     def _check_input_data(self, X, y):
         raise NotImplementedError
 
+    # -- input validation (SomVQ.py:122 / SomClassifier.py: check_array / check_X_y) -------------
+    def _finite_check_on_device(self) -> bool:
+        """Whether the "no NaN, no infinity" part of sklearn's input validation can ride on the column sums
+        the initialisation takes from the resident samples anyway (one host pass over X saved: 0.15 s of a
+        1.3 s fit at 1e6 x 784): the default backend, one process, the whole X resident."""
+        from .backend import HipBackend
+
+        return (self.backend is None or isinstance(self.backend, HipBackend)) and dist_info()[1] == 1 \
+            and not self.sharded_input
+
+    @staticmethod
+    def _finite_kw(check: bool) -> dict:
+        """`ensure_all_finite` (scikit-learn >= 1.6) / `force_all_finite` (before) of check_array."""
+        import inspect
+
+        from sklearn.utils import check_array
+
+        name = "ensure_all_finite" if "ensure_all_finite" in inspect.signature(check_array).parameters \
+            else "force_all_finite"
+        return {name: check}
+
+    def _assert_finite_from_moments(self, X, mom) -> None:
+        """The deferred half of the validation: a NaN or an infinity anywhere in a column shows in the column's
+        sum (NaN / +-inf / NaN for +inf and -inf together).  Only when a sum is not finite is sklearn's own
+        check run -- it raises its usual ValueError, or passes (finite values whose sum overflowed)."""
+        if not getattr(self, "_finite_deferred", False):
+            return
+        self._finite_deferred = False
+        if mom is None or not (np.isfinite(mom[0]).all() and np.isfinite(mom[1]).all()):
+            from sklearn.utils import assert_all_finite
+
+            assert_all_finite(X)
+
     def _label_prototypes(self, X, y) -> None:
         raise NotImplementedError
 
@@ -238,8 +271,12 @@ class BaseSom(BaseEstimator):
             self._col_s2 = self._all_reduce_f64(((loc - mean) ** 2).sum(axis=0)).astype(data.dtype)
         elif self._shard == (0, data.shape[0]) and hasattr(engine, "column_moments"):
             mom = engine.column_moments()
+            if not on_device:
+                self._assert_finite_from_moments(data, mom)
             if mom is not None:
                 self._col_s2 = mom[1]
+        if getattr(self, "_finite_deferred", False):   # (no moments from the device after all: the host check now)
+            self._assert_finite_from_moments(data, None)
         if self._col_s2 is None and on_device:
             raise ValueError("a DeviceSamples fit needs float32 / float64 resident samples")
         self.growing_threshold_ = self._calculate_growing_threshold(data)

@@ -373,22 +373,22 @@ __global__ __launch_bounds__(AT) void segsum_kernel(
 //    in list order.  Sums, their order of additions and the scalar partials are those of segsum_kernel bit
 //    for bit (the two search forms must leave bit-identical prototypes).
 // A slice none of whose rows needs a distance skips the chain altogether.
-#ifndef CHAIN_STAMPS
-#define CHAIN_STAMPS 0   // experiment builds (tools/build_variant.sh): 1 = per-phase s_memtime sums of a workgroup, left in
-#endif                   // `dist` of the chunk's first rows as -(1e12 + phase 1e10 + cycles) (tools/chain_stamps.py)
-#if CHAIN_STAMPS
-#define CSTAMP(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); if (tid == 0) { st_acc[k] += now_ - st_last; } st_last = now_; } while (0)
+// Stamps and experiment switches of segsum_chain_kernel live in experiments.h, which only the experiment builds of
+// tools/build_variant.sh compile (-DDBGSOM_EXPERIMENTS ...); the shipped kernel carries four empty macros.
+#ifdef DBGSOM_EXPERIMENTS
+#include "experiments.h"
 #else
+#define CSTAMP_DECL
 #define CSTAMP(k)
+#define CSTAMP_LOADS_LANDED
+#define CSTAMP_FLUSH(dist, rows_s, n)
+#define CHAIN_PAD 0
 #endif
 #ifndef CHAIN_CB
 #define CHAIN_CB 4        // k-steps per batch of the chain's operand ring
 #endif
 #ifndef CHAIN_CW
 #define CHAIN_CW ((c >> 8) & 3u)
-#endif
-#ifndef CHAIN_PAD
-#define CHAIN_PAD 0        // experiment builds: bytes of LDS a workgroup asks for on top (fewer workgroups per CU)
 #endif
 #ifndef CHAIN_OCC
 #define CHAIN_OCC 3       // wavefronts per SIMD the one-group kernel is compiled for
@@ -449,9 +449,7 @@ __global__ __launch_bounds__(AT, G == 1 ? CHAIN_OCC : 2) void segsum_chain_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t c = blockIdx.x;
     if (c >= chunk_pre[M]) return;  // uniform per workgroup
-#if CHAIN_STAMPS
-    uint64_t st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
-#endif
+    CSTAMP_DECL;
     {   // the chunk's neuron: the one j with chunk_pre[j] <= c < chunk_pre[j + 1] -- every thread looks at its share of
         // the table at once (one round trip instead of the ten of a binary search by one thread)
         const int per = (M + AT - 1) / AT;
@@ -528,10 +526,7 @@ __global__ __launch_bounds__(AT, G == 1 ? CHAIN_OCC : 2) void segsum_chain_kerne
             }
         }
         CSTAMP(1);
-#if CHAIN_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        CSTAMP(2);
-#endif
+        CSTAMP_LOADS_LANDED;
         if ((need_mask >> (s0 / SR)) & 1u) {   // (uniform)
             // ---- the chain: ranges of 64 column groups through two LDS buffers
             // (rows behind the slice's end: zeros, written by row lane 0 -- never garbage in a B column)
@@ -646,13 +641,7 @@ __global__ __launch_bounds__(AT, G == 1 ? CHAIN_OCC : 2) void segsum_chain_kerne
         CSTAMP(6);
     }
     __syncthreads();
-#if CHAIN_STAMPS
-    CSTAMP(7);
-    if (tid == 0 && n >= 11) {
-        for (int k = 0; k < 10; ++k) dist[rows_s[k]] = -(1e12 + 1e10 * k + (double)st_acc[k]);
-        dist[rows_s[10]] = -(1e12 + 1e10 * 10 + (double)n);
-    }
-#endif
+    CSTAMP_FLUSH(dist, rows_s, n);
     if (tid == AT - 1) {  // the scalar partials, in list order
         double sk = 0.0, se = 0.0;
         for (int p = 0; p < n; ++p) { sk += kw_s[p]; se += dist_s[p]; }

@@ -116,6 +116,67 @@ int launch_bucket_sort(const int64_t *idx, int64_t N, int64_t M, int32_t *order,
                        hipStream_t s);
 const uint32_t *bucket_sort_seg_start(const void *ws, int64_t N, int64_t M);
 // the filtered search with everything the engine may add to the public dbgsom_bmu_filtered call
+// optional per-stage timing of dbgsom_bmu_filtered (bench / profiling): events on the caller's stream
+struct StageTimer {
+    bool enabled = false, valid = false;
+    hipEvent_t ev[6] = {};
+    bool created = false;
+    void mark(int k, hipStream_t s) {
+        if (!enabled) return;
+        if (!created) { for (auto &e : ev) (void)hipEventCreate(&e); created = true; }
+        (void)hipEventRecord(ev[k], s);
+    }
+    void destroy() {
+        if (created) for (auto &e : ev) (void)hipEventDestroy(e);
+        created = false; valid = false;
+    }
+};
+
+// a second stream for launches that may overlap (per FilterAux, created on first use; if it cannot be
+// created the work simply stays on the caller's stream)
+struct SideStream {
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t forked = nullptr, joined = nullptr, joined2 = nullptr, mid = nullptr;
+    hipEvent_t gap_fork = nullptr, gap_done = nullptr;   // the prototype gaps beside the seed pre-pass
+    int state = 0;  // 0 untried, 1 ready, -1 unavailable
+    int device = -1;
+    bool ready() {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (state == 0) {
+            device = dev;
+            // (lowest priority: what runs here is off the critical path -- a few long chains beside the
+            //  caller's stream -- and must not starve the short dependent kernels there: at equal priority the
+            //  bucket sort between the refinement and the pair kernel took 0.5 ms instead of 0.06)
+            int prio_low = 0, prio_high = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+            state = (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_low) == hipSuccess &&
+                     hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio_low) == hipSuccess &&
+                     hipEventCreateWithFlags(&forked, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&joined2, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&mid, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&gap_fork, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&gap_done, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
+        }
+        return state == 1 && dev == device;  // (another device current than the one the streams live on: no fork)
+    }
+    void destroy() {
+        if (state == 1) {
+            (void)hipStreamDestroy(stream); (void)hipStreamDestroy(stream2);
+            for (hipEvent_t e : {forked, joined, joined2, mid, gap_fork, gap_done}) (void)hipEventDestroy(e);
+        }
+        state = 0;
+    }
+};
+
+struct FilterAux {
+    StageTimer timer;
+    SideStream side;
+    void destroy() { timer.destroy(); side.destroy(); }
+};
+int filter_stage_ms(FilterAux &aux, double *ms5);   // [0] slice W + tables, [1] pre-pass, [2] bucket sort, [3] sweep, [4] exact stage
+
 struct FilteredCall {
     const void *X = nullptr;
     int x_dtype = 0;
@@ -152,6 +213,8 @@ struct FilteredCall {
     // never run on this map may leave the whole map a candidate, and the exact stage over such lists costs
     // twice the all-pairs search the caller can run instead
     double guard_mean = 0.0;
+    // stage timer and side streams of the caller (a context's own); nullptr: this thread's
+    FilterAux *aux = nullptr;
 };
 constexpr int DBGSOM_LISTS_LONG = 1000;   // (internal status of launch_bmu_filtered, never crosses the ABI)
 int launch_bmu_filtered(const FilteredCall &call);

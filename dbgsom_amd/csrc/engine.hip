@@ -351,12 +351,8 @@ struct dbgsom_ctx {
     bool ev_created = false, ev_valid = false;
     double filter_ms[5] = {0, 0, 0, 0, 0};
     bool filter_ms_valid = false;
+    FilterAux faux;   // this context's stage timer and side streams of the filtered search (FilteredCall::aux)
 };
-
-extern "C" {
-int dbgsom_filter_timing(int enable);
-int dbgsom_bmu_filtered_stage_ms(double *ms5);
-}
 
 namespace {
 
@@ -491,6 +487,8 @@ int stage_weights(dbgsom_ctx *c, const double *W_host, int64_t M, int64_t d, int
     return launch_row_sqnorms(c->Wb[c->cur].p, DBGSOM_F64, M, dp, dp, c->ww.as<double>(), c->stream);
 }
 
+double bearable_mean(const dbgsom_ctx *c, int64_t M);
+
 // k = 1 search through the int8 filter; seeds = previous winners when `hinted`
 int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t M, int round_f32,
                  const int64_t *prev_idx, const int32_t *order, int64_t *idx, double *dist, bool may_probe = false,
@@ -508,6 +506,7 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     // seeds = the last epoch's winners, and their exact distances are still around: the pruning
     // bound need not read X for samples whose prototype has hardly moved
     FilteredCall call;
+    call.aux = &c->faux;
     if (may_probe && prev_idx && c->dist_bound_valid && dist == c->dist.as<double>() && M <= PRUNE_MAX_M &&
         (c->planes_used == 0 || c->last_probed) && c->Wb[c->distW_buf].p) {
         TRY(c->shiftb.reserve((size_t)M * 8));
@@ -571,7 +570,7 @@ int run_filtered(dbgsom_ctx *c, Samples &s, DevBuf &ws, const double *W, int64_t
     const int arm_row = prev_idx ? 2 : (c->last_seed_full ? 1 : 0);
     if (may_probe && c->algorithm == DBGSOM_ALG_AUTO && call.k == 1 &&
         (c->planeM != M || isnan(c->arm_seen[arm_row][c->planes_used])))
-        call.guard_mean = (double)c->max_mean_candidates;
+        call.guard_mean = bearable_mean(c, M);
     const int rc_f = launch_bmu_filtered(call);
     c->last_filter_M = M; c->last_filter_N = s.N; c->last_filter_d = s.dp; c->last_filter_ws = ws.p;
     if (rc_f == DBGSOM_LISTS_LONG) {
@@ -712,6 +711,15 @@ bool shard_smoothing(const dbgsom_ctx *c, int64_t M, int64_t dp) {
     return c->shard_smooth == 1 || 2.0 * (double)M * (double)M * (double)dp >= 8e9;
 }
 
+// The mean list length `auto` bears before it goes back to the all-pairs kernel: the option (320), and never more
+// than half the map -- in the cost model's units an arm costs (its sweep) x M + 12.5 x (mean list) against the
+// all-pairs kernel's 8.4 x M, so lists beyond ~0.5 .. 0.65 M lose to it whatever the arm.  (A young, still collapsed
+// map of a growing fit: at M = 130 .. 260 the lists were 0.75 M and a filtered epoch cost 8 .. 14 ms against 6 .. 7
+// of all pairs -- profiles/r04_fit_trace_before.txt.)
+double bearable_mean(const dbgsom_ctx *c, int64_t M) {
+    return fmin((double)c->max_mean_candidates, 0.5 * (double)M);
+}
+
 // What the next filtered search runs: an ARM = (seeds, digit planes).  Seeds: 0 = the cheap stateless
 // pre-pass (every 4th .. 64th prototype on three 64-feature blocks), 1 = the full one (every
 // prototype, every feature: one more sweep), 2 = the previous epoch's winners (not a choice: whenever
@@ -760,7 +768,7 @@ void adapt_arms(dbgsom_ctx *c, double mean, int64_t M, int64_t N) {
     c->arm_known[row][p] = c->arm_seen[row][p] = mean;
     c->arm_age[row][p] = 0;
     // (an arm that left more than the policy bears gets its next look late: a look at it costs an all-pairs epoch)
-    if (mean > (double)c->max_mean_candidates) c->arm_wait[row][p] = 128;
+    if (mean > bearable_mean(c, M)) c->arm_wait[row][p] = 128;
     if (!isnan(c->last_epoch_ms))   // (the mean of the last two looks: one epoch's clock jitters by a few per cent)
         c->arm_ms[row][p] = isnan(c->arm_ms[row][p]) ? c->last_epoch_ms : 0.5 * (c->arm_ms[row][p] + c->last_epoch_ms);
     if (c->last_probed) {  // what arm 0 would have produced from the same seeds
@@ -905,10 +913,10 @@ void update_policy(dbgsom_ctx *c, double list_sum, double probe_sum, double retr
         // (not while an arm that has never run on this map is up next: on unclustered data the strong corner --
         //  good seeds and a finer sweep -- is what works, and eight all-pairs epochs in front of its first try
         //  cost forty settled ones)
-        if (c->best_mean > (double)c->max_mean_candidates && !c->exploring_next) {  // exponential back-off, capped
+        if (c->best_mean > bearable_mean(c, M) && !c->exploring_next) {  // exponential back-off, capped
             c->filter_fail = c->filter_fail < 6 ? c->filter_fail + 1 : 6;
             c->filter_backoff = FILTER_BACKOFF << (c->filter_fail - 1);
-        } else if (c->best_mean > (double)c->max_mean_candidates) {
+        } else if (c->best_mean > bearable_mean(c, M)) {
             // (exploring)
         } else {
             c->filter_fail = 0;
@@ -1052,7 +1060,7 @@ int smooth_and_fetch(dbgsom_ctx *c, int64_t M, double sigma, int layout, int fla
     TRY(sync(c));
     c->ev_valid = c->timing != 0;
     if (c->timing && c->last_filtered) {
-        c->filter_ms_valid = dbgsom_bmu_filtered_stage_ms(c->filter_ms) == DBGSOM_OK;
+        c->filter_ms_valid = filter_stage_ms(c->faux, c->filter_ms) == DBGSOM_OK;
     } else {
         c->filter_ms_valid = false;
     }
@@ -1094,12 +1102,13 @@ int resident_bmu(dbgsom_ctx *c, const double *W_host, int64_t M, int k, int roun
             if (v == v && !(lists0 <= v)) lists0 = v;
         }
     if (k == 2 && filter_applies(c, M) && M <= PRUNE_MAX_M && M >= 2 && c->last_filter_M == M && lists0 == lists0 &&
-        lists0 <= (double)c->max_mean_candidates) {
+        lists0 <= bearable_mean(c, M)) {
         const bool hint = (c->algorithm == DBGSOM_ALG_AUTO || c->algorithm == DBGSOM_ALG_FILTERED_HINT) &&
                           c->hint_valid && c->hintM <= M;
         TRY(ensure_planes(c, s));
         TRY(c->filt_ws.reserve_zeroed(dbgsom_bmu_filtered_workspace_bytes(s.N, s.dp, M), c->stream));
         FilteredCall call;
+        call.aux = &c->faux;
         call.X = s.Xb; call.x_dtype = s.bdtype; call.N = s.N; call.d = s.dp; call.ldx = s.dp;
         call.xx = s.xx.as<double>(); call.xplanes = s.planes.p; call.W = W; call.M = M; call.ww = c->ww.as<double>();
         call.prev_idx = hint ? c->idx[c->icur].as<int64_t>() : nullptr;
@@ -1164,8 +1173,8 @@ int dbgsom_ctx_destroy(dbgsom_ctx *c) {
     if (!c) return DBGSOM_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->timing) (void)dbgsom_filter_timing(0);
     drop_rccl(c);
+    c->faux.destroy();
     c->xs.release(); c->xq.release();
     DevBuf *bufs[] = CTX_DEVBUFS(c);
     for (DevBuf *b : bufs) b->release();
@@ -1191,7 +1200,8 @@ int dbgsom_ctx_set_option(dbgsom_ctx *c, const char *name, int64_t v) {
     } else if (!strcmp(name, "timing")) {
         c->timing = v != 0;
         c->ev_valid = false;
-        TRY(dbgsom_filter_timing(c->timing));
+        c->faux.timer.enabled = c->timing != 0;
+        c->faux.timer.valid = false;
     } else if (!strcmp(name, "graph")) {
         c->use_graph = v != 0;
     } else if (!strcmp(name, "defer")) {

@@ -39,20 +39,6 @@ constexpr int SCHED_SUM = 2 * SCHED_BINS + 6;  // (8-byte aligned: the counters 
 constexpr int RF_CTR = 4;  // u64 counters of the refinement (2d): pairs | refined workgroups | left to the MFMA stage | -
 static_assert(SCHED_CTR % 2 == 0, "the 64-bit counters of the refinement sit behind the schedule's");
 constexpr int SW_MAX_KT = 1024;   // k-tiles that selection handles (d <= 65536)
-#ifndef SUBSET_EXPERIMENT
-// Diagnostic builds of this file (never the shipped library): -DSUBSET_EXPERIMENT=<bits> /
-// -DSWEEP_EXPERIMENT=<bits> switch single resources off to see what a kernel's time is made of,
-// or add s_memtime stamps; run them through DBGSOM_LIB=<that .so> tools/sweep_stage_times.py.
-#define SUBSET_EXPERIMENT 0  // 1 no X DMA, 2 no W DMA, 4 no MFMA, 8 no LDS reads, 16 no barrier,
-// 32 return at once, 64 half occupancy, 128 stamps (tools/subset_stamps.py)
-#endif
-#ifndef SWEEP_EXPERIMENT
-#define SWEEP_EXPERIMENT 0  // 4 no MFMA, 8 no chunk epilogue,
-// 64 (with 8) products dead, 256 in-kernel s_memtime stamps (tools/sweep_stamps.py), 512 passing
-// pairs (tools/sweep_survivors.py), 1024 stamps in sweep4_i8_kernel (tools/sweep4_stamps.py),
-// 2048 sweep4_i8_kernel reads the fragments of every second k-step only (LDS share of its time),
-// 4096 sweep4_i8_kernel streams the same 1024 X rows in every workgroup (share of the X re-reads)
-#endif
 
 // plane rows are padded to whole k-tiles, at least two of them (the sweep's ring runs three tiles
 // ahead and keeps three chunk tables)
@@ -504,10 +490,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     uint32_t *mask = reinterpret_cast<uint32_t *>(smem + L::OFF_MASK);
     int *misc = reinterpret_cast<int *>(smem + L::OFF_MISC);
 
-#if SWEEP_EXPERIMENT & 256
-    const uint64_t k_start = __builtin_amdgcn_s_memtime();
-    uint64_t k_pro = 0, k_fill = 0, k_loop = 0;
-#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -636,10 +618,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         }
     }
     double bestv[2] = {INFINITY, INFINITY};  // MODE 1: running arg-min of r~
-#if SWEEP_EXPERIMENT & 512
-    unsigned npass = 0;  // (sample, prototype) pairs that pass the marking test
-    if (tid == 0) misc[3] = 0;
-#endif
     int bestj[2] = {0, 0};
 
     // ---- DMA sources: per plane, wave w loads X rows 16w..16w+15 and W rows 16w + 128u ..+15 ----
@@ -767,12 +745,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                 for (int jt = jh; jt < jh + 2 && jt < JT; ++jt)
 #pragma unroll
                     for (int it = 0; it < 2; ++it)
-#if SWEEP_EXPERIMENT & 4
-                        acc[jt][it][lv][0] += f.w[jt][lv - px][0] ^ f.x[it][px][1];
-#else
                         acc[jt][it][lv] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
                             f.w[jt][lv - px], f.x[it][px], acc[jt][it][lv], 0, 0, 0);
-#endif
                 between(g++);
             }
     };
@@ -790,9 +764,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     // [read k-step 0 of t + 1] [products of k-step 1].  Every read has 2 JT (1 + .. + NLV)
     // products of the other k-step in front of it, the barrier is the only point the matrix pipe
     // drains.
-#if SWEEP_EXPERIMENT & 256
-    k_pro = __builtin_amdgcn_s_memtime();
-#endif
     const int n_pre = ntile < 3 ? ntile : 3;
     for (int u = 0; u < n_pre; ++u) issue_ops(0, DMA_TILE);
     {   // groups 1 and 2 may stay in flight (group 2 opens a chunk iff nkt == 2)
@@ -801,27 +772,12 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#if SWEEP_EXPERIMENT & 256
-    k_fill = __builtin_amdgcn_s_memtime();
-#endif
     Frags f0, f1;
     load_frags(0, 0, f0);
     // (measured, no effect beyond run-to-run noise: s_setprio for the later-slot wavefronts, slots
     // mixed across the SIMDs instead of by wavefront half)
     constexpr int N_GROUPS = NLV * (NLV + 1) / 2 * ((JT + 1) / 2);  // product groups per k-step
     const int dma_slot = (wave >= 4 && N_GROUPS > 1) ? 1 : 0;  // group behind which this wave issues DMAs
-#if SWEEP_EXPERIMENT & 256
-    __shared__ unsigned wstamps[2 * 10 * 5];
-    const uint64_t w_start = __builtin_amdgcn_s_memtime();
-    const bool stamper = lane == 0 && (wave == 0 || wave == 4);
-#define WSTAMP(k) if (stamper && t >= 16 && t < 26) wstamps[(wave >> 2) * 50 + (t - 16) * 5 + (k)] = (unsigned)__builtin_amdgcn_s_memtime()
-    __shared__ unsigned estamps[4 * 4];
-    int e_seq = 0;
-#define ESTAMP(k) if (stamper && wave == 0 && e_seq < 4) estamps[e_seq * 4 + (k)] = (unsigned)__builtin_amdgcn_s_memtime()
-#else
-#define WSTAMP(k)
-#define ESTAMP(k)
-#endif
     int r_kt = 0, r_cseq = 0, r_chunk = c0, r_stage = 0;
     for (int t = 0; t < ntile; ++t) {
         const int r_next = (r_stage == (FSTAGES - 1) * L::STAGE) ? 0 : r_stage + L::STAGE;
@@ -830,7 +786,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         // Every wave issues half of a tile's DMAs in each half tile (front half of tile t + 3
         // behind the barrier, back half in the first half of the next tile); waves 0-3 (one per
         // SIMD) do so behind the first product group, their SIMD mates 4-7 behind the second.
-        WSTAMP(0);
         const bool back_now = t >= 1 && t + 2 < ntile;
         products(f0, [&](int g) {  // the reads of k-step 1 go behind the first product group
             if (g == 0) {
@@ -844,14 +799,11 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
         __builtin_amdgcn_sched_barrier(0);
         // (after the last tile this block is a no-op on stale data: no branch, so that the
         // compiler's LDS wait counting sees one path)
-        WSTAMP(1);
         if (t + 2 < ntile) wait_vm(DMA_TILE + ((r_kt + 2 == nkt) ? 1 : 0));
         else wait_vm(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        WSTAMP(2);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        WSTAMP(3);
         const bool front_now = t + 3 < ntile;
         products(f1, [&](int g) {
             if (g == 0) {
@@ -868,28 +820,7 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             __builtin_amdgcn_sched_barrier(0);
         });
 
-        WSTAMP(4);
         if (r_kt == nkt - 1) {
-#if SWEEP_EXPERIMENT & 8
-            if (t >= 0) {  // keep the products alive at (almost) no cost
-                int x = 0;
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                    for (int it = 0; it < 2; ++it)
-#pragma unroll
-                        for (int lv = 0; lv < NLV; ++lv)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) { x ^= acc[jt][it][lv][r]; acc[jt][it][lv][r] = 0; }
-#if !(SWEEP_EXPERIMENT & 64)
-                if (x == 0x12345678) misc[2] = x;
-#endif
-                r_kt = 0;
-                r_stage = r_next;
-                continue;
-            }
-#endif
-            ESTAMP(0);
             const int jc = r_chunk * BJ;
             const double *ytab = reinterpret_cast<const double *>(smem + L::OFF_TAB + r_cseq * 2 * L::TAB);
             const double *ctb = ytab + BJ;
@@ -928,7 +859,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                     for (int it = 0; it < 2; ++it) A_i[it] = thr_s[wi * 64 + it * 32 + lc];
                 }
             }
-            ESTAMP(1);
             // all table reads and compares of a 32-prototype tile first (bits), the LDS atomics
             // after them: a possible atomic between two elements pins every later table read
             // behind it and exposes one LDS round trip per element.
@@ -960,14 +890,8 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                             if constexpr (MODE == 0) {
                                 const double Tp = sweep_T_scaled<PLANES>(acc[jt][it][0][r], acc[jt][it][L1][r],
                                                                          acc[jt][it][L2][r]);
-#if SWEEP_EXPERIMENT & 512
-                                const uint64_t b1 = __builtin_amdgcn_ballot_w64(!((A_i[it] * c4[i] + y4[i]) > s_i[it] * Tp));
-                                npass += __popcll(b1);
-                                pass |= b1;
-#else
                                 // (a NaN marks: a seed that is a NaN row of W gives no bound, not an empty list)
                                 pass |= __builtin_amdgcn_ballot_w64(!((A_i[it] * c4[i] + y4[i]) > s_i[it] * Tp));
-#endif
                             } else {
                                 const double T = combine(acc[jt][it][0][r], acc[jt][it][L1][r], acc[jt][it][L2][r]);
                                 const double rv = y4[i] - s_i[it] * (c4[i] * T);  // r~ - |x_i|^2
@@ -989,7 +913,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
                     }
                 }
             }
-            ESTAMP(2);
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
@@ -1001,18 +924,11 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             r_chunk = (r_chunk + 1 == nchunk) ? 0 : r_chunk + 1;
             r_cseq = (r_cseq == 2) ? 0 : r_cseq + 1;
             load_frags(r_next, 0, f0);
-            ESTAMP(3);
-#if SWEEP_EXPERIMENT & 256
-            ++e_seq;
-#endif
         }
         r_kt = (r_kt == nkt - 1) ? 0 : r_kt + 1;  // a select: see sweep4_i8_kernel
         r_stage = r_next;
     }
 
-#if SWEEP_EXPERIMENT & 256
-    k_loop = __builtin_amdgcn_s_memtime();
-#endif
     if constexpr (MODE == 1) {
         // seed = arg-min of r~ over the 2 lane halves and the 4 prototype wavefronts
         __syncthreads();
@@ -1044,9 +960,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
     }
 
     // ---- compact the marked prototypes, ascending ------------------------------------------------
-#if SWEEP_EXPERIMENT & 512
-    if (lane == 0) atomicAdd(&misc[3], (int)npass);
-#endif
     __syncthreads();
     if (wave == 0) {
         uint32_t base = 0;
@@ -1074,22 +987,6 @@ __global__ __launch_bounds__(FNT, 2) void sweep_i8_kernel(
             // sum of the list lengths (what the engine's policy looks at: 8 bytes D2H instead of nb x 4)
             atomicAdd(reinterpret_cast<unsigned long long *>(sched_ctr + SCHED_SUM), (unsigned long long)base);
         }
-#if SWEEP_EXPERIMENT & 512
-        if (lane == 0) reinterpret_cast<unsigned *>(out + 512)[0] = (unsigned)misc[3];
-#endif
-#if SWEEP_EXPERIMENT & 256
-        {   // stamps of waves 0 and 4 behind the list: uint32 at uint16 offset 512 of this row
-            unsigned *dbg = reinterpret_cast<unsigned *>(out + 512);
-            for (int e = lane; e < 100; e += 64) dbg[e] = wstamps[e] - wstamps[0];
-            if (lane == 0) {
-                dbg[130] = (unsigned)(__builtin_amdgcn_s_memtime() - k_start);
-                dbg[131] = (unsigned)(k_pro - k_start);
-                dbg[132] = (unsigned)(k_fill - k_pro);
-                dbg[133] = (unsigned)(k_loop - k_fill);
-                for (int q = 0; q < 16; ++q) dbg[134 + q] = estamps[q] - estamps[(q / 4) * 4];
-            }
-        }
-#endif
     }
 }
 
@@ -1172,9 +1069,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
         const int r = 16 * (XI * wave + u) + (lane >> 2);
         const int64_t xpos = (p0 + r < N) ? (p0 + r) : (N - 1);
         i_dr[u] = sample_at(xpos);
-#if SWEEP_EXPERIMENT & 4096
-        i_dr[u] &= 1023;  // timing experiment: every workgroup's X rows come from the same 1024 (L2 hits; results are wrong)
-#endif
         dc[u] = (lane & 3) ^ ((r >> 2) & 3);
     }
     int64_t i_il[2];
@@ -1335,13 +1229,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
     struct Frags { v4i_t x[2], w[JT]; };
     auto load_frags = [&](int stage_off, int ks, Frags &f) {
         const char *stage = smem + stage_off;
-#if SWEEP_EXPERIMENT & 2048
-        if (ks == 1) {  // timing experiment: half of the fragment reads (results are wrong)
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt) f.w[jt] = f.x[jt & 1];
-            return;
-        }
-#endif
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt)
             f.w[jt] = *reinterpret_cast<const v4i_t *>(stage + (woff[jt] ^ (ks * 32)));
@@ -1390,20 +1277,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
     asm volatile("" ::: "memory");
     Frags f0, f1;
     load_frags(0, 0, f0);
-#if SWEEP_EXPERIMENT & 1024
-    // (inside the tail of the mask area -- M <= 512 in this build -- so that two workgroups still fit a CU)
-    unsigned *s4stamps = reinterpret_cast<unsigned *>(smem + L::OFF_MASK + 64);
-    const bool stamper = lane == 0 && wave < 4;
-#define S4STAMP(k) if (stamper && t >= 16 && t < 26) s4stamps[wave * 60 + (t - 16) * 6 + (k)] = (unsigned)__builtin_amdgcn_s_memtime()
-#else
-#define S4STAMP(k)
-#endif
     int r_kt = 0, r_chunk = c0, r_stage = 0;
     bool tab_pending = false;  // a table DMA was issued in the previous tile's second half
     for (int t = 0; t < ntile; ++t) {
         const int r_next = (r_stage == (FSTAGES - 1) * L::STAGE) ? 0 : r_stage + L::STAGE;
         const bool back_now = t >= 1 && t + 2 < ntile;
-        S4STAMP(0);
         products(f0, [&](int g) {
             if (g == 0) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -1416,14 +1294,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
         __builtin_amdgcn_sched_barrier(0);
         // own DMAs of tile t + 1 landed: what may stay in flight is tile t + 2 (and the table piece
         // issued behind the previous barrier, which sits between tiles t + 2 and t + 3 in the queue)
-        S4STAMP(1);
         if (t + 2 < ntile) wait_vm(DMA_TILE + (tab_pending ? 1 : 0));
         else wait_vm(0);
-        S4STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        S4STAMP(3);
         tab_pending = false;
         const bool front_now = t + 3 < ntile;
         products(f1, [&](int g) {
@@ -1439,7 +1314,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
             __builtin_amdgcn_sched_barrier(0);
         });
 
-        S4STAMP(4);
         if (r_kt == nkt - 1) {
             // the table pieces of this chunk: own piece landed (at most the 9 DMAs issued behind it
             // are in flight), then everybody's
@@ -1633,12 +1507,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sweep4_i8_kernel(  // (HIP: t
             // sum of the list lengths (what the engine's policy looks at: 8 bytes D2H instead of nb x 4)
             atomicAdd(reinterpret_cast<unsigned long long *>(sched_ctr + SCHED_SUM), (unsigned long long)base);
         }
-#if SWEEP_EXPERIMENT & 1024
-        {   // stamps of the four waves behind the list: uint32 at uint16 offset 512 of this row
-            unsigned *dbg = reinterpret_cast<unsigned *>(out + 512);
-            for (int e = lane; e < 240; e += 64) dbg[e] = s4stamps[e] - s4stamps[0];
-        }
-#endif
     }
 }
 
@@ -2086,14 +1954,6 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
     constexpr int S_XT = RW * XROW, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 / 16 KB (SPLIT: half) + 2 JTL KB
     static_assert(NS >= 3 && NS <= 8, "3 .. 8 stages");
     __shared__ __attribute__((aligned(16))) char smem[NS * S_STAGE];
-#if SUBSET_EXPERIMENT & 32
-    return;
-#endif
-#if SUBSET_EXPERIMENT & 128
-    const uint64_t t_start = __builtin_amdgcn_s_memtime();
-    const uint64_t r_start = __builtin_amdgcn_s_memrealtime();
-    uint64_t t_loop = 0, t_loop_end = 0;
-#endif
     // this class's slice of the schedule (2b): entry blockIdx.x of it, nothing beyond its end
     const uint32_t *range = sched_range + 2 * (3 - JTL);
     const unsigned entry = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
@@ -2166,14 +2026,8 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
         }
         const int k0 = i_kt * KT;
         char *stage = smem + i_stage;
-#if SUBSET_EXPERIMENT & 1
-        if (i_step + i_kt < 3)
-#endif
 #pragma unroll
         for (int u = 0; u < XD; ++u) fdma16(xsrc[u] + k0, stage + 1024 * (XD * wave + u));
-#if SUBSET_EXPERIMENT & 2
-        if (i_step + i_kt < 3)
-#endif
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             if (u < n_wdma) fdma16(wrow[u] + k0, stage + S_XT + 1024 * (wq0 + u));
@@ -2214,16 +2068,7 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
     // 65-entry list in 48-entry steps: 48 + 17 -- two tiles, not three), tiles behind its end are skipped
     int jtl_eff = JTL;
     if constexpr (JTL > 1) { const int rem = (cnt + 15) / 16; jtl_eff = rem < JTL ? rem : JTL; }
-#if SUBSET_EXPERIMENT & 128
-    t_loop = __builtin_amdgcn_s_memtime();
-    __shared__ unsigned stamps[13 * 5];
-    const bool stamper = tid == 0;
-#define STAMP(k) if (stamper && t >= 8 && t < 21) stamps[(t - 8) * 5 + (k)] = (unsigned)__builtin_amdgcn_s_memtime()
-#else
-#define STAMP(k)
-#endif
     for (int t = 0; t < ntile; ++t) {
-        STAMP(0);
         // each wavefront waits for ITS OWN DMAs of tile t, the barrier then covers everybody's: what may stay
         // in flight are the tiles issued behind it -- NS - 2 of them, fewer at the end of the walk
         {
@@ -2242,25 +2087,14 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef DBGSOM_WAIT_BEHIND
         }
-        STAMP(1);
-#if !(SUBSET_EXPERIMENT & 16)
         __builtin_amdgcn_s_barrier();
-#endif
-        STAMP(2);
         asm volatile("" ::: "memory");
         if (t + (NS - 1) < ntile) issue();
-        STAMP(3);
         const char *stage = smem + r_stage;
         r_stage = (r_stage == (NS - 1) * S_STAGE) ? 0 : r_stage + S_STAGE;
 #pragma unroll
         for (int ks = 0; ks < KT / 4; ++ks) {
             double a[JTL], b[IT];
-#if SUBSET_EXPERIMENT & 8
-#pragma unroll
-            for (int u = 0; u < JTL; ++u) a[u] = xi[0] + u;
-#pragma unroll
-            for (int u = 0; u < IT; ++u) b[u] = xi[u];
-#else
 #pragma unroll
             for (int u = 0; u < JTL; ++u) {
                 const int ca = (2 * ks + (lq >> 1)) ^ a_swz[u];
@@ -2276,21 +2110,15 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
                     b[u] = *reinterpret_cast<const double *>(stage + b_off[u] + cb * 16);
                 }
             }
-#endif
 #pragma unroll
             for (int jt = 0; jt < JTL; ++jt) {
                 if (JTL > 1 && K == 1 && jt > 0 && jt >= jtl_eff) continue;   // (uniform: no entries in this tile)
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
-#if SUBSET_EXPERIMENT & 4
-                    acc[jt][it][0] += a[jt] * b[it];
-#else
                     acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt], b[it], acc[jt][it],
                                                                        0, 0, 0);
-#endif
             }
         }
-        STAMP(4);
         if (kt == nkt - 1) {
             // list entries and |w|^2 of the lane's candidates, 4 at a time: loads first (clamped
             // positions, no branches), so that their latencies overlap
@@ -2351,21 +2179,10 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
                 double dv = sqrt(best[it].v[u]);
                 if (round_f32) dv = (double)(float)dv;
                 idx_out[isamp[it] * K + u] = (best[it].j[u] == 0x7fffffff) ? (int64_t)-1 : (int64_t)best[it].j[u];
-#if SUBSET_EXPERIMENT & 128
-                if (dv == -1.0) dist_out[isamp[it] * K + u] = dv;
-#else
                 dist_out[isamp[it] * K + u] = dv;
-#endif
             }
         }
     }
-#if SUBSET_EXPERIMENT & 128
-    t_loop_end = __builtin_amdgcn_s_memtime();
-        __syncthreads();
-        if (tid < 65 && p0 + 128 <= N) dist_out[p0 + tid] = (double)(stamps[tid] - stamps[0]);
-        if (tid == 65 && p0 + 128 <= N) dist_out[p0 + 65] = (double)cnt;
-        if (tid == 66 && p0 + 128 <= N) { dist_out[p0 + 66] = (double)r_start; dist_out[p0 + 67] = (double)__builtin_amdgcn_s_memrealtime(); dist_out[p0 + 68] = (double)__smid(); dist_out[p0 + 69] = (double)(__builtin_amdgcn_s_memtime() - t_start); dist_out[p0 + 70] = (double)(t_loop - t_start); dist_out[p0 + 71] = (double)(t_loop_end - t_start); }
-#endif
 }
 
 #include "refine.h"
@@ -2495,51 +2312,12 @@ static int launch_slice(const void *A, int dtype, int64_t rows, int64_t d, int64
 
 using namespace dbgsom;
 
-// optional per-stage timing of dbgsom_bmu_filtered (bench / profiling): events on the caller's stream
+// The per-caller state of the filtered search -- stage timer, side streams -- is a FilterAux (common.h): a context
+// owns one (FilteredCall::aux), so two contexts driven by one thread keep their own timings and each keeps the
+// side-stream overlap on its own device.  Callers of the raw device-level ABI (dbgsom_bmu_filtered,
+// dbgsom_filter_timing), which has no handle to hang it on, share this thread's.
 namespace {
-struct StageTimer {
-    bool enabled = false, valid = false;
-    hipEvent_t ev[6] = {};
-    bool created = false;
-    void mark(int k, hipStream_t s) {
-        if (!enabled) return;
-        if (!created) { for (auto &e : ev) (void)hipEventCreate(&e); created = true; }
-        (void)hipEventRecord(ev[k], s);
-    }
-};
-thread_local StageTimer g_timer;
-
-// a second stream for launches that may overlap (per thread, created on first use; if it cannot be
-// created the work simply stays on the caller's stream)
-struct SideStream {
-    hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t forked = nullptr, joined = nullptr, joined2 = nullptr, mid = nullptr;
-    hipEvent_t gap_fork = nullptr, gap_done = nullptr;   // the prototype gaps beside the seed pre-pass
-    int state = 0;  // 0 untried, 1 ready, -1 unavailable
-    int device = -1;
-    bool ready() {
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (state == 0) {
-            device = dev;
-            // (lowest priority: what runs here is off the critical path -- a few long chains beside the
-            //  caller's stream -- and must not starve the short dependent kernels there: at equal priority the
-            //  bucket sort between the refinement and the pair kernel took 0.5 ms instead of 0.06)
-            int prio_low = 0, prio_high = 0;
-            (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-            state = (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_low) == hipSuccess &&
-                     hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio_low) == hipSuccess &&
-                     hipEventCreateWithFlags(&forked, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&joined, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&joined2, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&mid, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&gap_fork, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&gap_done, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
-        }
-        return state == 1 && dev == device;  // a thread that moved to another device: no fork
-    }
-};
-thread_local SideStream g_side;
+thread_local dbgsom::FilterAux g_aux;
 }  // namespace
 
 extern "C" {
@@ -2548,19 +2326,9 @@ extern "C" {
  * dbgsom_bmu_filtered_stage_ms returns their durations for the LAST call, in milliseconds:
  * [0] slice W + tables, [1] coarse pre-pass (0 when a hint was given), [2] bucket sort,
  * [3] int8 sweep, [4] exact search on the candidates. */
-int dbgsom_filter_timing(int enable) { g_timer.enabled = enable != 0; g_timer.valid = false; return DBGSOM_OK; }
+int dbgsom_filter_timing(int enable) { g_aux.timer.enabled = enable != 0; g_aux.timer.valid = false; return DBGSOM_OK; }
 
-int dbgsom_bmu_filtered_stage_ms(double *ms5) {
-    DBGSOM_REQUIRE(ms5, "null pointer");
-    if (!g_timer.enabled || !g_timer.valid) { set_error("no timed dbgsom_bmu_filtered call"); return DBGSOM_ESTATE; }
-    DBGSOM_HIP_CHECK(hipEventSynchronize(g_timer.ev[5]));
-    for (int k = 0; k < 5; ++k) {
-        float ms = 0.f;
-        DBGSOM_HIP_CHECK(hipEventElapsedTime(&ms, g_timer.ev[k], g_timer.ev[k + 1]));
-        ms5[k] = ms;
-    }
-    return DBGSOM_OK;
-}
+int dbgsom_bmu_filtered_stage_ms(double *ms5) { return dbgsom::filter_stage_ms(g_aux, ms5); }
 
 size_t dbgsom_filter_planes_bytes(int64_t rows, int64_t d) {
     if (rows < 1 || d < 1) return 0;
@@ -2618,6 +2386,19 @@ int dbgsom_bmu_filtered(const void *X_dev, int x_dtype, int64_t N, int64_t d, in
 
 }  // extern "C"
 
+int dbgsom::filter_stage_ms(FilterAux &aux, double *ms5) {
+    DBGSOM_REQUIRE(ms5, "null pointer");
+    StageTimer &t = aux.timer;
+    if (!t.enabled || !t.valid) { set_error("no timed dbgsom_bmu_filtered call"); return DBGSOM_ESTATE; }
+    DBGSOM_HIP_CHECK(hipEventSynchronize(t.ev[5]));
+    for (int k = 0; k < 5; ++k) {
+        float ms = 0.f;
+        DBGSOM_HIP_CHECK(hipEventElapsedTime(&ms, t.ev[k], t.ev[k + 1]));
+        ms5[k] = ms;
+    }
+    return DBGSOM_OK;
+}
+
 int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
     const void *X_dev = call.X; const int x_dtype = call.x_dtype; const int64_t N = call.N, d = call.d, ldx = call.ldx;
     const double *xx_dev = call.xx; const void *xplanes_dev = call.xplanes; const double *W_dev = call.W;
@@ -2625,6 +2406,9 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
     const int32_t *order_dev = call.order; int seed_stride = call.seed_stride, sweep_planes = call.sweep_planes;
     const int round_f32 = call.round_f32; int64_t *idx_dev = call.idx; double *dist_dev = call.dist;
     void *workspace_dev = call.ws; const size_t workspace_bytes = call.ws_bytes; void *stream = (void *)call.stream;
+    FilterAux &aux = call.aux ? *call.aux : g_aux;
+    StageTimer &g_timer = aux.timer;
+    SideStream &g_side = aux.side;
     const double *g_hint_dist = call.hint_dist, *g_hint_shift = call.hint_shift;
     // 8 wavefronts of 64 x 64 tiles (<= 128 VGPRs: four wavefronts per SIMD, two workgroups per CU)
     // or 4 of 64 x 128 (DBGSOM_SWEEP_WAVES=4; two wavefronts per SIMD).  Measured, ms per launch,
@@ -3015,13 +2799,6 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
 
 extern "C" {
 
-#if SWEEP_EXPERIMENT & (256 | 512 | 1024)
-size_t dbgsom_debug_ulist_offset(int64_t N, int64_t d, int64_t M) {
-    FilterWs f;
-    carve_filter(&f, (char *)nullptr, N, d, M);
-    return (size_t)((char *)f.ulist - (char *)nullptr);
-}
-#endif
 
 /* (internal, engine.hip) device address of the sum of the candidate-list lengths of the last call */
 const unsigned long long *dbgsom_filter_count_sum_ptr(const void *workspace_dev, int64_t N, int64_t d, int64_t M) {

@@ -74,14 +74,6 @@ struct RefineCfg {
 #ifndef REFINE_DEPHASE
 #define REFINE_DEPHASE 1
 #endif
-#ifndef REFINE_STAMPS
-#define REFINE_STAMPS 0   // experiment builds: phase times (s_memtime ticks, 100 MHz) of a few workgroups via printf
-#endif
-#if REFINE_STAMPS & 1
-#define R_STAMP(k) do { if (tid == 0) r_st[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define R_STAMP(k)
-#endif
 template <int NJ, int JT>
 __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     const int8_t *__restrict__ xplanes, const double *__restrict__ sx, const double *__restrict__ xres,
@@ -119,10 +111,6 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
     int cnt_next = (int)ucount[group_next];
     for (int entry = q_first; entry < q_hi; entry += q_step) {
     if (entry != q_first) __syncthreads();  // the previous workgroup's tables are done with
-#if REFINE_STAMPS & 1
-    uint64_t r_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    R_STAMP(0);
     const int group = __builtin_amdgcn_readfirstlane(group_next);
     const int64_t p0 = (int64_t)group * 128;
     const int cnt_all = __builtin_amdgcn_readfirstlane(cnt_next);  // 1 <= cnt_all <= RF_SEGS ROWS (class_fill_kernel)
@@ -161,11 +149,7 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         const int r = 16 * blk + (lane >> 2);
         int64_t p = p0 + r;
         p = p < N ? p : N - 1;
-#if REFINE_STAMPS & 2   // timing experiment: every workgroup streams the same 128 sample rows (L2 hits; results are wrong)
-        xsrc[u] = xplanes + pl * xps + (size_t)r * dpad + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
-#else
         xsrc[u] = xplanes + pl * xps + (size_t)order[p] * dpad + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
-#endif
         xdst[u] = pl * C::X_PLANE + blk * 1024;
     }
     // W (k-tile-major, the chunks of a row already swizzled by ITS index): op ow = u NW + wave, block
@@ -230,7 +214,6 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[jt][lv][r] = 0;
 
-    R_STAMP(1);
     issue();
     if (nkt > 1) issue();
     {   // second hop, under the DMAs in flight: the tables of the list entries, the samples' constants
@@ -281,7 +264,6 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         }
         if (!issue_first && t + 2 < nkt) issue();
     }
-    R_STAMP(2);
     __syncthreads();  // every wavefront is done with the ring: v_ij takes its place
     float *vm = reinterpret_cast<float *>(smem);
     {
@@ -309,7 +291,6 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         }
     }
     __syncthreads();
-    R_STAMP(3);
     {
         // selection: SP threads per sample, each over a contiguous part of the list (parts in list order, so
         // that candidates come out ascending); scratch behind the v_ij matrix, inside the ring's bytes
@@ -338,7 +319,6 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
             pm[part * 128 + sidx] = m;
             plm[part * 128 + sidx] = lm;
         }
-        R_STAMP(6);
         __syncthreads();
         double eps2 = 0.0;
         if (act) {
@@ -373,7 +353,6 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
             ppos[part * 128 + sidx] = pos;
             pn[part * 128 + sidx] = n;
         }
-        R_STAMP(7);
         __syncthreads();
         if (act && part == 0) {  // this segment's candidates (ascending) behind those of the earlier ones
             int n = 0;
@@ -426,7 +405,6 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         }
     }
     }  // (segments)
-    R_STAMP(4);
     if (tid < 128 && p0 + tid < N) {
         // the candidates of all segments against the minimum of the whole list
         const int64_t isamp = isamp_s[tid];
@@ -481,14 +459,6 @@ __global__ __launch_bounds__(NJ * 256, NJ < 2 ? 2 : NJ) void refine_i8_kernel(
         atomicAdd(rf_ctr + 0, (unsigned long long)misc[8]);
         atomicAdd(rf_ctr + 1, 1ull);
     }
-#if REFINE_STAMPS & 1
-    R_STAMP(5);
-    if (tid == 0 && (blockIdx.x % 97) == 3)
-        printf("refine<%d,%d> wg %d entry %d cnt %d: setup %d loop %d vm %d select %d (min %d mark %d merge %d) final %d  (ticks)\n", NJ, JT,
-               (int)blockIdx.x, entry, cnt_all, (int)(r_st[1] - r_st[0]), (int)(r_st[2] - r_st[1]), (int)(r_st[3] - r_st[2]),
-               (int)(r_st[4] - r_st[3]), (int)(r_st[6] - r_st[3]), (int)(r_st[7] - r_st[6]), (int)(r_st[4] - r_st[7]),
-               (int)(r_st[5] - r_st[4]));
-#endif
     }  // (queue)
 }
 

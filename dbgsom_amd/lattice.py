@@ -193,10 +193,39 @@ class GrowingLattice:
             self.has_error = np.append(self.has_error, True)
             self.epoch_created = np.append(self.epoch_created, epoch)
         x, y = pos
+        fresh = []
         for nb in ((x, y + 1), (x, y - 1), (x - 1, y), (x + 1, y)):
             if nb in g.nodes:
+                if not g.has_edge(pos, nb):
+                    fresh.append(nb)
                 g.add_edge(pos, nb)
-        self._hops = None
+        self._grow_hops(pos, fresh)
+
+    def _grow_hops(self, pos, fresh):
+        """Keep the all-pairs hop counts current across an insertion instead of recomputing them (a
+        breadth-first search from every node, 1.3 ms at 250 neurons, per growth step): a NEW last node v
+        with neighbours S has d(v, x) = 1 + min_s d(s, x), and a shortest path that did not exist before
+        passes through v exactly once, d'(x, y) = min(d(x, y), d(x, v) + d(v, y)) -- the same integers.
+        A fresh array every time (the backend keys its copy on the array's identity)."""
+        H = self._hops
+        if H is None:
+            return                                  # nothing to keep: recomputed when next asked for
+        m, i = H.shape[0], self._index[pos]
+        if m == len(self._index):                   # an occupied position was rewritten
+            if fresh:
+                self._hops = None                   # (an edge nobody had drawn yet: recompute)
+            return
+        if i != m or m != len(self._index) - 1:     # (not a new LAST node: recompute)
+            self._hops = None
+            return
+        rows = [self._index[nb] for nb in fresh]
+        dv = 1.0 + H[rows].min(axis=0) if rows else np.full(m, np.inf)
+        Hn = np.empty((m + 1, m + 1))
+        np.minimum(H, dv[:, None] + dv[None, :], out=Hn[:m, :m])
+        Hn[m, :m] = dv
+        Hn[:m, m] = dv
+        Hn[m, m] = 0.0
+        self._hops = Hn
 
     # -- pruning / export -----------------------------------------------------------------------
     def remove(self, dead_nodes):

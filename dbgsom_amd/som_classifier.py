@@ -21,7 +21,10 @@ class SomClassifier(BaseSom, TransformerMixin, ClassifierMixin):
     """Directed batch growing SOM classifier (see ``BaseSom`` for parameters)."""
 
     def _check_input_data(self, X, y):
-        X, y = check_X_y(X=X, y=y, ensure_min_samples=4, dtype=[np.float64, np.float32])
+        # (X's finite check rides on the device's column sums when it can; y is checked here as ever)
+        self._finite_deferred = self._finite_check_on_device()
+        X, y = check_X_y(X=X, y=y, ensure_min_samples=4, dtype=[np.float64, np.float32],
+                         **self._finite_kw(not self._finite_deferred))
         return X, y
 
     def _label_prototypes(self, X, y) -> None:

@@ -18,7 +18,10 @@ class SomVQ(BaseSom, ClusterMixin, TransformerMixin):
 
     def _check_input_data(self, X, y=None):
         # float32 is kept as float32 (the device stores it as such); anything else -> float64
-        X = check_array(array=X, ensure_min_samples=4, dtype=[np.float64, np.float32])
+        # (the finite check rides on the device's column sums when it can: BaseSom._assert_finite_from_moments)
+        self._finite_deferred = self._finite_check_on_device()
+        X = check_array(array=X, ensure_min_samples=4, dtype=[np.float64, np.float32],
+                        **self._finite_kw(not self._finite_deferred))
         return X, None  # any y is ignored
 
     def _label_prototypes(self, X, y=None) -> None:

@@ -97,6 +97,28 @@ def test_fit_reproduces_the_reference_up_to_its_blas_dependent_tie():
     assert int(tr[e, 4]) == int(g["trace_n_dead"][e]) + 1
 
 
+def test_hop_distances_kept_current_across_insertions_equal_a_recomputation():
+    """GrowingLattice keeps the all-pairs hop counts (nx.floyd_warshall_numpy's values, BaseSom.py:367,401) current
+    across insertions (new node: d(v, .) = 1 + min over its neighbours, d' = min(d, d(., v) + d(v, .))) instead of a
+    breadth-first search from every node per growth step; random growth, rewritten positions included."""
+    from dbgsom_amd.lattice import GrowingLattice
+
+    rng = np.random.default_rng(0)
+    lat = GrowingLattice(rng.normal(size=(4, 3)))
+    first = lat.hop_distances()
+    for step in range(400):
+        nodes = lat.nodes
+        n = nodes[rng.integers(len(nodes))]
+        dx, dy = [(0, 1), (0, -1), (1, 0), (-1, 0)][rng.integers(4)]
+        lat._insert((n[0] + dx, n[1] + dy), rng.normal(size=3), step)
+        if rng.random() < 0.4:
+            kept = lat.hop_distances()
+            lat._hops = None
+            assert np.array_equal(kept, lat.hop_distances()), step
+            assert kept is not first                     # a fresh array per change (the backend keys on identity)
+    assert len(lat) > 60
+
+
 def test_growth_trace_node_by_node():
     g = gi.load("blobs_dead")
     X, _ = gi.case_X("blobs_dead")

@@ -39,9 +39,15 @@ def fit_profile(X, **kw):
         be = est._engine()
         log = be._log_epoch
 
+        t_last = [time.perf_counter()]
+
         def spy():
             log()
-            sizes.append((be._last_M, be.filter_log[-1][0] if be.filter_log else "exact"))
+            now = time.perf_counter()
+            last = be.filter_log[-1] if be.filter_log else ("exact", None)
+            sizes.append((be._last_M, last[0], round((now - t_last[0]) * 1e3, 3), last[1] if len(last) > 1 else None,
+                          last[2] if len(last) > 2 else None))
+            t_last[0] = now
 
         be._log_epoch = spy
         t0 = time.perf_counter()
@@ -55,8 +61,9 @@ def fit_profile(X, **kw):
     top = sorted(calls.items(), key=lambda kv: -kv[1][1])[:6]
     return {
         "wall_s": wall, "epochs": int(est.n_iter_) + 1, "neurons_final": len(est.neurons_),
-        "neurons_max": max(m for m, _ in sizes), "growth_steps": len(est._growth_epochs),
-        "epochs_filtered": sum(1 for _, k in sizes if k == "filtered"),
+        "neurons_max": max(e[0] for e in sizes), "growth_steps": len(est._growth_epochs),
+        "epochs_filtered": sum(1 for e in sizes if e[1] == "filtered"),
+        "per_epoch": sizes if os.environ.get("DBGSOM_FIT_TRACE") else None,
         "in_abi_s": in_abi, "epoch_calls_s": epoch_s, "host_s": wall - in_abi, "host_share": (wall - in_abi) / wall,
         "pcie_bytes": {"samples_up": int(X.nbytes), "prototypes_up": int(tr["w_upload_bytes"]),
                        "prototypes_down": int(tr["w_download_bytes"]), "rows_written": int(tr["w_row_writes"])},
@@ -80,4 +87,15 @@ if __name__ == "__main__":
               convergence_iter=int(opts.get("convergence_iter", 1)),
               coarse_training_frac=float(opts.get("coarse_training_frac", 0.7)))
     fit_profile(X[:4000], **dict(kw, n_iter=10))   # warm up the library
-    print(json.dumps(fit_profile(X, **kw)))
+    if os.environ.get("DBGSOM_FIT_CPROFILE"):
+        import cProfile
+        import pstats
+
+        pr = cProfile.Profile()
+        pr.enable()
+        res = fit_profile(X, **kw)
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(28)
+        print(json.dumps(res))
+    else:
+        print(json.dumps(fit_profile(X, **kw)))

@@ -1,5 +1,5 @@
 """Per-stage HIP-event times of frozen-map epochs (bench workload), median over the steps; one JSON line.
-    [DBGSOM_LIB=exp_build/libdbgsom_x.so] python tools/stage_times.py c4 [steps=12] [algo=filtered] [rows=N] [opt=value ...]"""
+    [DBGSOM_LIB=exp_build/libdbgsom_x.so] python tools/stage_times.py c4 [steps=12] [algo=filtered] [rows=N] [map=RxC] [opt=value ...]"""
 import json
 import os
 import sys
@@ -20,6 +20,8 @@ steps = int(opts.pop("steps", 12))
 algo = opts.pop("algo", "filtered")
 take = int(opts.pop("rows", 0))
 n, d, rows, cols, seed, kind, _ = bench.WORKLOADS[name]
+if "map" in opts:   # another lattice on the workload's samples: map=8x8
+    rows, cols = (int(v) for v in opts.pop("map").split("x"))
 M = rows * cols
 dev = torch.device("cuda", 0)
 hip = HipBackend(0, algorithm=algo)
