@@ -16,8 +16,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def fit_profile(X, **kw):
-    """Fit SomVQ(**kw) on the host array X through the default backend; time every call of the C ABI."""
+def fit_profile(X, backend_opts=None, **kw):
+    """Fit SomVQ(**kw) on the host array X through the default backend (`backend_opts`: options of an explicit
+    HipBackend -- algorithm, refine, sweep_planes ... -- for experiments); time every call of the C ABI."""
     from dbgsom_amd import SomVQ, _native
 
     calls = {}
@@ -35,6 +36,13 @@ def fit_profile(X, **kw):
     _native.call = timed
     sizes = []
     try:
+        if backend_opts:
+            from dbgsom_amd.backend import HipBackend
+
+            hb = HipBackend(algorithm=backend_opts.pop("algorithm", "auto"))
+            for k, v in backend_opts.items():
+                hb._set(k, int(v))
+            kw = dict(kw, backend=hb)
         est = SomVQ(**kw)
         be = est._engine()
         log = be._log_epoch
@@ -69,7 +77,8 @@ def fit_profile(X, **kw):
                        "prototypes_down": int(tr["w_download_bytes"]), "rows_written": int(tr["w_row_writes"])},
         "abi_top": {k: {"calls": v[0], "s": round(v[1], 4)} for k, v in top},
         "quantization_error": float(est.quantization_error_), "topographic_error": float(est.topographic_error_),
-        "params": {k: (v if isinstance(v, (int, float, str, bool)) or v is None else str(v)) for k, v in kw.items()},
+        "params": {k: (v if isinstance(v, (int, float, str, bool)) or v is None else str(v)) for k, v in kw.items()
+                   if k != "backend"},
     }
 
 
@@ -86,6 +95,7 @@ if __name__ == "__main__":
               spreading_factor=float(opts.get("spreading_factor", 0.9)),
               convergence_iter=int(opts.get("convergence_iter", 1)),
               coarse_training_frac=float(opts.get("coarse_training_frac", 0.7)))
+    bopts = {k: opts[k] for k in ("algorithm", "refine", "sweep_planes", "defer") if k in opts}
     fit_profile(X[:4000], **dict(kw, n_iter=10))   # warm up the library
     if os.environ.get("DBGSOM_FIT_CPROFILE"):
         import cProfile
@@ -93,9 +103,9 @@ if __name__ == "__main__":
 
         pr = cProfile.Profile()
         pr.enable()
-        res = fit_profile(X, **kw)
+        res = fit_profile(X, dict(bopts) or None, **kw)
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(28)
         print(json.dumps(res))
     else:
-        print(json.dumps(fit_profile(X, **kw)))
+        print(json.dumps(fit_profile(X, dict(bopts) or None, **kw)))
