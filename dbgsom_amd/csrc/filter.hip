@@ -1579,8 +1579,13 @@ constexpr int PRUNE_MAX_M = 8192;  // the gap matrix: 4 M^2 bytes (256 MB here)
 // (2^15 + 2^7 + 1/2 + 3 u F) / F
 constexpr double PLANE0_ERR = 32897.0 / (127.0 * 65536.0) * (1.0 + 1e-6);
 
-// gap[j ldg + p] for a 64 x 64 tile of (p, j); one wavefront per tile, operands straight from the
-// k-tile-major top plane (L2-resident), P = D0 . D0
+// gap[j ldg + p] for a (32 NB) x (32 NB) tile of (p, j); one wavefront per tile, operands straight from the
+// k-tile-major top plane (L2-resident), P = D0 . D0.  NB = 2 (64 x 64 tiles) where that fills the chip; maps below
+// ~2000 prototypes have fewer such tiles than four per CU -- 256 at M = 1024, one lone wavefront per CU walking its
+// k loop and a float64 epilogue of 64 values per lane with nothing to overlap them with (141 us at C4, on the
+// critical path of every epoch that starts from hints) -- and take NB = 1: four times the wavefronts, a quarter
+// of the epilogue each
+template <int NB>
 __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict__ wt, int w_rows, int dpad, int M, int d,
                                                        const double *__restrict__ tw, const double *__restrict__ wn0,
                                                        const double *__restrict__ ww, float *__restrict__ gap, int ldg,
@@ -1588,31 +1593,32 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
     // nnub[p] (k = 2 searches; float32 bits, +inf before the launch): an UPPER bound of the distance from
     // prototype p to its nearest other prototype, from the same products: |w^_p - w^_j| + e_p + e_j
     const int lane = threadIdx.x, lc = lane & 31, lh = lane >> 5;
-    const int pb = blockIdx.x * 64, jb = blockIdx.y * 64;
+    constexpr int TS = 32 * NB;
+    const int pb = blockIdx.x * TS, jb = blockIdx.y * TS;
     const int nks = dpad / 32;  // dpad is a multiple of 64
-    const int8_t *base[2][2];   // [side: 0 = p, 1 = j][32-row block]: this lane's row
-    int sw[2][2];
+    const int8_t *base[2][NB];   // [side: 0 = p, 1 = j][32-row block]: this lane's row
+    int sw[2][NB];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < NB; ++b) {
         const int rp = pb + b * 32 + lc, rj = jb + b * 32 + lc;
         base[0][b] = wt + (size_t)rp * FKT; sw[0][b] = (rp >> 2) & 3;
         base[1][b] = wt + (size_t)rj * FKT; sw[1][b] = (rj >> 2) & 3;
     }
-    struct Fr { v4i_t v[2][2]; };  // [side][block]
+    struct Fr { v4i_t v[2][NB]; };  // [side][block]
     auto load = [&](int ks, Fr &f) {
         const size_t tile = (size_t)(ks >> 1) * w_rows * FKT;
         const int c = (ks & 1) * 2 + lh;
 #pragma unroll
         for (int sd = 0; sd < 2; ++sd)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < NB; ++b)
                 f.v[sd][b] = *reinterpret_cast<const v4i_t *>(base[sd][b] + tile + ((c ^ sw[sd][b]) << 4));
     };
-    v16i_t P[2][2];  // [jt][it]
+    v16i_t P[NB][NB];  // [jt][it]
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
+        for (int it = 0; it < NB; ++it)
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[jt][it][r] = 0;
     Fr f0, f1, f2, f3;
@@ -1621,18 +1627,18 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
     for (int ks = 0; ks < nks; ks += 4) {  // two k-steps in flight behind the two being multiplied
         if (ks + 2 < nks) { load(ks + 2, f2); load(ks + 3, f3); }
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < NB; ++it) {
                 P[jt][it] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0.v[1][jt], f0.v[0][it], P[jt][it], 0, 0, 0);
                 P[jt][it] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f1.v[1][jt], f1.v[0][it], P[jt][it], 0, 0, 0);
             }
         if (ks + 2 >= nks) break;
         if (ks + 4 < nks) { load(ks + 4, f0); load(ks + 5, f1); }
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < NB; ++it) {
                 P[jt][it] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f2.v[1][jt], f2.v[0][it], P[jt][it], 0, 0, 0);
                 P[jt][it] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f3.v[1][jt], f3.v[0][it], P[jt][it], 0, 0, 0);
             }
@@ -1641,7 +1647,7 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
     // the tile's 64 column prototypes: scale and digit norm once, through LDS (every lane needs 32 of them)
     __shared__ double tj_s[64], bj_s[64];
     {
-        const int j = jb + lane;
+        const int j = jb + lane;   // (NB = 1: the upper half is filled and never read)
         tj_s[lane] = j < M ? tw[j] : 0.0;
         // (a row with a NaN or an infinity has digits that mean nothing: 0 |w|^2 turns into a NaN and
         //  the pair gets "no gap known")
@@ -1649,14 +1655,14 @@ __global__ __launch_bounds__(64) void proto_gap_kernel(const int8_t *__restrict_
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NB; ++it) {
         const int p = pb + it * 32 + lc;
         const bool pok = p < M;
         const double tp = pok ? tw[p] : 0.0, Bp = pok ? wn0[p] + 0.0 * ww[p] : 0.0;
         const double ep = root_d * tp * PLANE0_ERR;
         float near_ub = INFINITY;
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int jl = jt * 32 + 4 * lh + (r & 3) + 8 * (r >> 2), j = jb + jl;
@@ -2506,8 +2512,12 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
     auto launch_gap = [&](hipStream_t gs) -> int {
         const unsigned gt = (unsigned)(f.Mg / 64);
         if (k2) DBGSOM_HIP_CHECK(hipMemsetAsync(f.nnub, 0x7f, (size_t)f.Mg * 4, gs));   // (0x7f7f7f7f: 3.4e38, "no bound")
-        hipLaunchKernelGGL(proto_gap_kernel, dim3(gt, gt), dim3(64), 0, gs, f.wt, (int)f.Mpad, dpad, (int)M, (int)d,
-                           f.wscale, f.wn0, ww_dev, f.gap, (int)f.Mg, k2 ? f.nnub : (uint32_t *)nullptr);
+        if (gt * gt >= 1024u)   // (four 64 x 64 tiles per CU and more: M >= 2048)
+            hipLaunchKernelGGL(proto_gap_kernel<2>, dim3(gt, gt), dim3(64), 0, gs, f.wt, (int)f.Mpad, dpad, (int)M, (int)d,
+                               f.wscale, f.wn0, ww_dev, f.gap, (int)f.Mg, k2 ? f.nnub : (uint32_t *)nullptr);
+        else
+            hipLaunchKernelGGL(proto_gap_kernel<1>, dim3(2 * gt, 2 * gt), dim3(64), 0, gs, f.wt, (int)f.Mpad, dpad, (int)M,
+                               (int)d, f.wscale, f.wn0, ww_dev, f.gap, (int)f.Mg, k2 ? f.nnub : (uint32_t *)nullptr);
         return DBGSOM_OK;
     };
     static const int gap_fork_env = [] {
