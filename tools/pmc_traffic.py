@@ -38,7 +38,8 @@ def per_kernel(root, counter):
 def main():
     workload, fdir, wdir = sys.argv[1], sys.argv[2], sys.argv[3]
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
-    entry = {"source": f"profiles/r03_{workload}_pmc_traffic.txt"}
+    tag = os.environ.get("CAMPAIGN_TAG", "r04")
+    entry = {"source": f"profiles/{tag}_{workload}_pmc_traffic.txt"}
     lines = [f"# workload {workload}, build {bench.source_hash()}: HBM bytes per launch = FETCH_SIZE KiB x 1024 x 2 "
              f"(gfx950 correction) + WRITE_SIZE KiB x 1024"]
     total = 0.0
@@ -57,7 +58,7 @@ def main():
     table = json.load(open(path)) if os.path.exists(path) else {}
     table.setdefault(bench.source_hash(), {})[workload] = entry
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
-    open(os.path.join(ROOT, "profiles", f"r03_{workload}_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(ROOT, "profiles", f"{tag}_{workload}_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
 
