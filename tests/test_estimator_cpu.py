@@ -260,3 +260,38 @@ def test_vertical_growth_builds_the_tree_the_reference_means_to():
     est = SomVQ(backend=OracleBackend("sklearn"), **gi.EST_KWARGS["vertical_blobs"]).fit(X)
     assert int(g["n_maps"]) > 1
     gi.check_vertical_tree(est, g)
+
+
+def test_bench_generators_in_chunks_are_the_whole_arrays():
+    """bench.py generates a workload's rows chunk by chunk (a C5 shard is 4 GB of float32: never whole on the host);
+    the chunks are the rows of `make_shard_numpy`, which SURVEY 8(d) defines -- any box regenerates the same inputs."""
+    import bench
+
+    for kind in ("blobs", "iso"):
+        for rank in (0, 3):
+            whole = bench.make_shard_numpy(250_003, 8, 77, kind, rank)
+            parts = np.concatenate([c for _, c in bench.iter_shard_numpy(250_003, 8, 77, kind, rank)])
+            assert np.array_equal(whole, parts)
+    a = bench.make_shard_numpy(1000, 8, 77, "blobs", 0)
+    b = bench.make_shard_numpy(1000, 8, 77, "blobs", 1)
+    assert not np.array_equal(a, b)          # another rank, other rows ...
+    ca = np.random.default_rng(77).standard_normal((32, 8)).astype(np.float32) * 4.0
+    assert np.abs(a[:, None, :] - ca[None]).sum(axis=2).min(axis=1).max() < 8 * 6.0   # ... around the same 32 centres
+
+
+def test_finite_check_keyword_follows_the_installed_scikit_learn():
+    """check_array's keyword was renamed (force_all_finite -> ensure_all_finite in scikit-learn 1.6): the estimator
+    passes whichever exists, and only defers the check to the device for the default backend in one process."""
+    import inspect
+
+    from sklearn.utils import check_array
+
+    kw = SomVQ._finite_kw(False)
+    (name, value), = kw.items()
+    assert name in inspect.signature(check_array).parameters and value is False
+    check_array(np.array([[np.nan, 1.0], [2.0, 3.0]]), **kw)       # accepted: the check is off
+    with pytest.raises(ValueError):
+        check_array(np.array([[np.nan, 1.0], [2.0, 3.0]]), **SomVQ._finite_kw(True))
+    assert SomVQ(backend=OracleBackend())._finite_check_on_device() is False
+    with pytest.raises(ValueError):                                  # the host check, as ever
+        SomVQ(backend=OracleBackend(), n_iter=3).fit(np.array([[np.inf, 1.0]] * 8))
