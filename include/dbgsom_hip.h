@@ -259,7 +259,10 @@ int dbgsom_ctx_destroy(dbgsom_ctx *ctx);
  * inequality, DBGSOM_PRUNE), "seed_stride" (0 = library default),
  * "timing" (1: HIP events around the phases of an epoch and the stages of the filter),
  * "filter_min_query_rows", "max_mean_candidates", "graph" (reserved: accepted and stored, no effect in this
- * build -- an epoch is 22-23 back-to-back launches on the context's stream and two forked ones).  Readable besides those: "n_samples", "features", "padded_features", "prototypes",
+ * build -- an epoch is 22-23 back-to-back launches on the context's stream and two forked ones), "refine" (0 off,
+ * 1 on, 2 by measurement: the per-sample refinement in front of the exact stage), "defer" (with the refinement: the
+ * distance of a sample it decided is evaluated inside the epoch's sums kernel; off by default), "shard_smooth".
+ * Readable besides those: "refined", "defer_epochs" (epochs whose sums kernel evaluated distances), "shard_epochs", "n_samples", "features", "padded_features", "prototypes",
  * "planes_cached", "planes_used" / "planes_next" (0 = no sweep), "seed_mode", "prune_retry", "hint_valid",
  * "filter_backoff", "plane_hold", "device_bytes", and the
  * PCIe traffic of the prototypes since the context was created: "w_upload_calls" / "w_upload_bytes"
