@@ -235,21 +235,25 @@ __global__ __launch_bounds__(SCW) void scatter_kernel(const int64_t *__restrict_
     }
 }
 
+// (non-temporal: every row is read exactly once by this kernel, 16 bytes per lane and whole cache lines per
+//  wavefront instruction -- streamed past the caches, segsum_kernel's 3.4 GB at C4 take 0.57 instead of 0.64 ms)
 template <typename XT, int VEC>
 __device__ __forceinline__ void load_vec(const XT *__restrict__ src, double (&v)[VEC]) {
     if constexpr (sizeof(XT) == 4 && VEC == 4) {
-        const float4 t4 = *reinterpret_cast<const float4 *>(src);
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const f4_t t4 = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(src));
         v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
     } else if constexpr (sizeof(XT) == 8 && VEC == 2) {
-        const double2 t2 = *reinterpret_cast<const double2 *>(src);
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const d2_t t2 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(src));
         v[0] = t2.x; v[1] = t2.y;
     } else if constexpr (sizeof(XT) == 2 && VEC == 8) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(src);
-        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+        typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+        const u4_t a = __builtin_nontemporal_load(reinterpret_cast<const u4_t *>(src));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[2 * e] = (double)__uint_as_float(w[e] << 16);
-            v[2 * e + 1] = (double)__uint_as_float(w[e] & 0xffff0000u);
+            v[2 * e] = (double)__uint_as_float(a[e] << 16);
+            v[2 * e + 1] = (double)__uint_as_float(a[e] & 0xffff0000u);
         }
     } else {
         static_assert(VEC == 1, "unsupported vector width");

@@ -1781,7 +1781,8 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
                     const int ch = ch0 + 8 * u;
                     const bool ok = live[rh + r] && ch < nch;
                     const v4i_t zero = {0, 0, 0, 0};
-                    xv[r][u] = ok ? *reinterpret_cast<const v4i_t *>(xrow[rh + r] + ch * 16) : zero;
+                    // (non-temporal: a sample's plane row is read once, eight lanes to a cache line)
+                    xv[r][u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(xrow[rh + r] + ch * 16)) : zero;
                     wv[r][u] = ok ? *reinterpret_cast<const v4i_t *>(wrow[rh + r] + (size_t)(ch >> 2) * w_rows * FKT +
                                                                      (((ch & 3) ^ wswz[rh + r]) << 4)) : zero;
                 }
