@@ -21,6 +21,7 @@
 // 3. subset_exact_kernel (bmu_dma-style f64 MFMA on gathered rows): exact arg-min of each sample
 //    over its workgroup's marked prototypes = exact arg-min over all prototypes.
 #include <math.h>
+#include <type_traits>
 
 #include "bmu_common.h"
 
@@ -1941,7 +1942,7 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
 // workgroups of a small sample set (one or two rounds of workgroups) take as many stages as fit four
 // workgroups per CU: 6 / 5 / 4 for JTL = 1 / 2 / 3 (C2 stage 99 -> 91 us, a 125 k-row share of C4 235 -> 212).
 template <typename XT, int JTL, int NWV, int SPLIT = 1, int K = 1, int NS = 3>
-__global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
+__global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) void subset_exact_kernel(
     const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
     const double *__restrict__ W, int M, const double *__restrict__ ww,
     const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
@@ -2061,110 +2062,118 @@ __global__ __launch_bounds__(NWV * 64, 4) void subset_exact_kernel(
         }
     }
 
-    d4_t acc[JTL][IT];
-#pragma unroll
-    for (int jt = 0; jt < JTL; ++jt)
-#pragma unroll
-        for (int it = 0; it < IT; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
-
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
         if (ntile > u) issue();
-    int kt = 0, st = 0, r_stage = 0;
-    // 16-prototype tiles of the running step that hold list entries: the last step of a list is short (a
-    // 65-entry list in 48-entry steps: 48 + 17 -- two tiles, not three), tiles behind its end are skipped
-    int jtl_eff = JTL;
-    if constexpr (JTL > 1) { const int rem = (cnt + 15) / 16; jtl_eff = rem < JTL ? rem : JTL; }
-    for (int t = 0; t < ntile; ++t) {
-        // each wavefront waits for ITS OWN DMAs of tile t, the barrier then covers everybody's: what may stay
-        // in flight are the tiles issued behind it -- NS - 2 of them, fewer at the end of the walk
-        {
-            const int behind = ntile - 1 - t;
+    int t = 0, r_stage = 0;
+    // One step of the list: its nkt k-tiles on the first JE 16-prototype tiles, then the candidates' distances.
+    // JE is a compile-time figure -- the last step of a list is short (65 entries in 48-entry steps: 48 + 17, two
+    // tiles, not three), and a uniform branch per tile INSIDE the k loop kept the compiler from issuing the
+    // fragment reads of a tile ahead of its products (one exposed LDS round trip per product group).
+    auto run_step = [&](auto je_c, const int st) {
+        constexpr int JE = decltype(je_c)::value;
+        d4_t acc[JE][IT];
+#pragma unroll
+        for (int jt = 0; jt < JE; ++jt)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
+        for (int kt = 0; kt < nkt; ++kt, ++t) {
+            // each wavefront waits for ITS OWN DMAs of tile t, the barrier then covers everybody's: what may stay
+            // in flight are the tiles issued behind it -- NS - 2 of them, fewer at the end of the walk
+            {
+                const int behind = ntile - 1 - t;
 #define DBGSOM_WAIT_BEHIND(Q)                                                                        \
-            if (n_wdma == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Q) * (XD + 2)) : "memory");      \
-            else if (n_wdma == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Q) * (XD + 1)) : "memory"); \
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Q) * XD) : "memory")
-            static_assert((NS - 2) * (XD + 2) <= 63, "vmcnt is a 6-bit counter");
-            if (behind >= NS - 2) { DBGSOM_WAIT_BEHIND(NS - 2); }
-            else if (NS > 3 && behind == 1) { DBGSOM_WAIT_BEHIND(1); }
-            else if (NS > 4 && behind == 2) { DBGSOM_WAIT_BEHIND(NS > 4 ? 2 : 0); }
-            else if (NS > 5 && behind == 3) { DBGSOM_WAIT_BEHIND(NS > 5 ? 3 : 0); }
-            else if (NS > 6 && behind == 4) { DBGSOM_WAIT_BEHIND(NS > 6 ? 4 : 0); }
-            else if (NS > 7 && behind == 5) { DBGSOM_WAIT_BEHIND(NS > 7 ? 5 : 0); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (n_wdma == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Q) * (XD + 2)) : "memory");      \
+                else if (n_wdma == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Q) * (XD + 1)) : "memory"); \
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Q) * XD) : "memory")
+                static_assert((NS - 2) * (XD + 2) <= 63, "vmcnt is a 6-bit counter");
+                if (behind >= NS - 2) { DBGSOM_WAIT_BEHIND(NS - 2); }
+                else if (NS > 3 && behind == 1) { DBGSOM_WAIT_BEHIND(1); }
+                else if (NS > 4 && behind == 2) { DBGSOM_WAIT_BEHIND(NS > 4 ? 2 : 0); }
+                else if (NS > 5 && behind == 3) { DBGSOM_WAIT_BEHIND(NS > 5 ? 3 : 0); }
+                else if (NS > 6 && behind == 4) { DBGSOM_WAIT_BEHIND(NS > 6 ? 4 : 0); }
+                else if (NS > 7 && behind == 5) { DBGSOM_WAIT_BEHIND(NS > 7 ? 5 : 0); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef DBGSOM_WAIT_BEHIND
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + (NS - 1) < ntile) issue();
-        const char *stage = smem + r_stage;
-        r_stage = (r_stage == (NS - 1) * S_STAGE) ? 0 : r_stage + S_STAGE;
-#pragma unroll
-        for (int ks = 0; ks < KT / 4; ++ks) {
-            double a[JTL], b[IT];
-#pragma unroll
-            for (int u = 0; u < JTL; ++u) {
-                const int ca = (2 * ks + (lq >> 1)) ^ a_swz[u];
-                a[u] = *reinterpret_cast<const double *>(stage + a_off[u] + ca * 16);
             }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + (NS - 1) < ntile) issue();
+            const char *stage = smem + r_stage;
+            r_stage = (r_stage == (NS - 1) * S_STAGE) ? 0 : r_stage + S_STAGE;
+            // every fragment of the tile first, then the products
+            double a[KT / 4][JE];
+            std::conditional_t<sizeof(XT) == 4, float, double> braw[KT / 4][IT];
 #pragma unroll
-            for (int u = 0; u < IT; ++u) {
-                if constexpr (sizeof(XT) == 4) {
-                    const int cb = ks ^ b_swz[u];
-                    b[u] = (double)*reinterpret_cast<const float *>(stage + b_off[u] + cb * 16);
-                } else {
-                    const int cb = (2 * ks + (lq >> 1)) ^ b_swz[u];
-                    b[u] = *reinterpret_cast<const double *>(stage + b_off[u] + cb * 16);
-                }
-            }
+            for (int ks = 0; ks < KT / 4; ++ks) {
 #pragma unroll
-            for (int jt = 0; jt < JTL; ++jt) {
-                if (JTL > 1 && K == 1 && jt > 0 && jt >= jtl_eff) continue;   // (uniform: no entries in this tile)
-#pragma unroll
-                for (int it = 0; it < IT; ++it)
-                    acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt], b[it], acc[jt][it],
-                                                                       0, 0, 0);
-            }
-        }
-        if (kt == nkt - 1) {
-            // list entries and |w|^2 of the lane's candidates, 4 at a time: loads first (clamped
-            // positions, no branches), so that their latencies overlap
-#pragma unroll
-            for (int jt = 0; jt < JTL; ++jt) {
-                int jv[4];
-                double yv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pos = st * SJ + jt * 16 + 4 * r + lq;
-                    jv[r] = (int)list[pos < cnt ? pos : cnt - 1];
+                for (int u = 0; u < JE; ++u) {
+                    const int ca = (2 * ks + (lq >> 1)) ^ a_swz[u];
+                    a[ks][u] = *reinterpret_cast<const double *>(stage + a_off[u] + ca * 16);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) yv[r] = ww[jv[r]];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pos = st * SJ + jt * 16 + 4 * r + lq;
-                    if (pos < cnt) {
-#pragma unroll
-                        for (int it = 0; it < IT; ++it) {
-                            double rv = (xi[it] + (-2.0 * acc[jt][it][r])) + yv[r];
-                            if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
-                            best[it].push(rv, jv[r]);  // list ascends -> j ascends per lane
-                        }
+                for (int u = 0; u < IT; ++u) {
+                    if constexpr (sizeof(XT) == 4) {
+                        const int cb = ks ^ b_swz[u];
+                        braw[ks][u] = *reinterpret_cast<const float *>(stage + b_off[u] + cb * 16);
+                    } else {
+                        const int cb = (2 * ks + (lq >> 1)) ^ b_swz[u];
+                        braw[ks][u] = *reinterpret_cast<const double *>(stage + b_off[u] + cb * 16);
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int jt = 0; jt < JTL; ++jt)
+            for (int ks = 0; ks < KT / 4; ++ks) {
 #pragma unroll
-                for (int it = 0; it < IT; ++it) acc[jt][it] = d4_t{0.0, 0.0, 0.0, 0.0};
-            kt = 0;
-            ++st;
-            if constexpr (JTL > 1) {
-                const int rem = (cnt - st * SJ + 15) / 16;
-                jtl_eff = rem < JTL ? (rem < 1 ? 1 : rem) : JTL;
+                for (int jt = 0; jt < JE; ++jt)
+#pragma unroll
+                    for (int it = 0; it < IT; ++it)
+                        acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks][jt], (double)braw[ks][it], acc[jt][it],
+                                                                           0, 0, 0);
             }
+        }
+        // list entries and |w|^2 of the lane's candidates, 4 at a time: loads first (clamped positions, no
+        // branches), so that their latencies overlap
+#pragma unroll
+        for (int jt = 0; jt < JE; ++jt) {
+            int jv[4];
+            double yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pos = st * SJ + jt * 16 + 4 * r + lq;
+                jv[r] = (int)list[pos < cnt ? pos : cnt - 1];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[r] = ww[jv[r]];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // (no branch around the use of the loaded values: a load that is consumed on some paths only is
+                //  still "in flight" for the compiler when the k loop starts again, and it then answers the first
+                //  reuse of its register -- a fragment read, a DMA address -- with s_waitcnt vmcnt(0): the ring drained
+                //  on every tile.  A position behind the end of the list pushes +inf, which never wins.)
+                const bool listed = st * SJ + jt * 16 + 4 * r + lq < cnt;
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    double rv = (xi[it] + (-2.0 * acc[jt][it][r])) + yv[r];
+                    if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
+                    best[it].push(listed ? rv : (double)INFINITY, jv[r]);  // list ascends -> j ascends per lane
+                }
+            }
+        }
+    };
+    for (int st = 0; st < nstep; ++st) {
+        // (K = 2 walks whole steps: tiles behind the end of the list hold no entries and are not pushed)
+        const int left = (cnt - st * SJ + 15) / 16;
+        if constexpr (JTL == 1 || K != 1) {
+            run_step(std::integral_constant<int, JTL>{}, st);
+        } else if constexpr (JTL == 2) {
+            if (left == 1) run_step(std::integral_constant<int, 1>{}, st);
+            else run_step(std::integral_constant<int, 2>{}, st);
         } else {
-            ++kt;
+            if (left == 1) run_step(std::integral_constant<int, 1>{}, st);
+            else if (left == 2) run_step(std::integral_constant<int, 2>{}, st);
+            else run_step(std::integral_constant<int, 3>{}, st);
         }
     }
 #pragma unroll
