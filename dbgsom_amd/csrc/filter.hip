@@ -1941,6 +1941,10 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
 // NS = stages of the ring (NS - 1 tiles in flight).  3 where the chip is full of workgroups; the 64-sample
 // workgroups of a small sample set (one or two rounds of workgroups) take as many stages as fit four
 // workgroups per CU: 6 / 5 / 4 for JTL = 1 / 2 / 3 (C2 stage 99 -> 91 us, a 125 k-row share of C4 235 -> 212).
+#ifndef DBGSOM_QUAD_MAX
+#define DBGSOM_QUAD_MAX 3
+#endif
+constexpr int QUAD_MAX = DBGSOM_QUAD_MAX;   // a last tile with up to 4 QUAD_MAX entries goes as groups of four
 template <typename XT, int JTL, int NWV, int SPLIT = 1, int K = 1, int NS = 3>
 __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) void subset_exact_kernel(
     const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
@@ -2043,24 +2047,21 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
         if (++i_kt == nkt) { i_kt = 0; ++i_step; }
     };
 
-    int a_off[JTL], a_swz[JTL], b_off[IT], b_swz[IT];
-#pragma unroll
-    for (int u = 0; u < JTL; ++u) {
-        const int ra = u * 16 + lr;
-        a_off[u] = S_XT + ra * 128 + (lq & 1) * 8;
-        a_swz[u] = (ra >> 1) & 7;
-    }
-#pragma unroll
-    for (int u = 0; u < IT; ++u) {
-        const int rb = wave * WS + u * 16 + lr;
-        if constexpr (sizeof(XT) == 4) {
-            b_off[u] = rb * XROW + lq * 4;
-            b_swz[u] = (rb >> 1) & 3;
-        } else {
-            b_off[u] = rb * XROW + (lq & 1) * 8;
-            b_swz[u] = (rb >> 1) & 7;
-        }
-    }
+    // Fragment addresses inside a stage.  A row of a tile is 128 bytes (W, float64 X) or 64 (float32 X) in 16-byte
+    // chunks, chunk c of row r stored at c ^ swizzle(r) with swizzle = (r >> 1) & 7 (& 3).  Tiles start at
+    // multiples of 16 rows and the rows of a group of four at multiples of 4, so the swizzle of a lane's row is the
+    // same in every tile, and the chunk of k-step ks is the chunk of k-step 0 with 2 ks (float32 X: ks) xor-ed in:
+    // ONE lane-dependent offset per operand, the tile as an immediate, the k-step as an xor of the final address
+    // (a stage is a multiple of 128 bytes) -- not a register per (tile, k-step).
+    const int hq = lq >> 1;
+    const int a_base = S_XT + lr * 128 + (lq & 1) * 8 + 16 * (hq ^ ((lr >> 1) & 7));
+    const int aq_row = lane & 3;   // (groups of four, below: rows 4 u + (lane & 3) behind the full tiles)
+    const int aq_base = S_XT + aq_row * 128 + (lq & 1) * 8 + 16 * (hq ^ (aq_row >> 1));
+    constexpr int B_TILE = 16 * XROW, B_KS = sizeof(XT) == 4 ? 16 : 32;
+    const int b_base = sizeof(XT) == 4 ? (wave * WS + lr) * XROW + lq * 4 + 16 * ((lr >> 1) & 3)
+                                       : (wave * WS + lr) * XROW + (lq & 1) * 8 + 16 * (hq ^ ((lr >> 1) & 7));
+    static_assert(S_STAGE % 128 == 0 && S_XT % 128 == 0, "the k-step is an xor of the address");
+    using xfrag_t = std::conditional_t<sizeof(XT) == 4, float, double>;
 
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
@@ -2070,9 +2071,23 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
     // JE is a compile-time figure -- the last step of a list is short (65 entries in 48-entry steps: 48 + 17, two
     // tiles, not three), and a uniform branch per tile INSIDE the k loop kept the compiler from issuing the
     // fragment reads of a tile ahead of its products (one exposed LDS round trip per product group).
-    auto run_step = [&](auto je_c, const int st) {
-        constexpr int JE = decltype(je_c)::value;
-        d4_t acc[JE][IT];
+    //
+    // NQ groups of FOUR prototypes behind the JE full tiles, on v_mfma_f64_4x4x4_4b: four 4x4x4 blocks per
+    // instruction, the same four prototypes in every block's A (row lane & 3 of the group, k = lane >> 4), the
+    // wavefront's 16 samples over the blocks' B columns -- the B fragment of the 16x16x4 form as it is -- and the
+    // result of sample (lane & 15) x prototype (lane >> 4) in one register pair: 16 cycles of the matrix pipe for
+    // four prototypes instead of 64 for a quarter-filled tile, the same sequential chain bit for bit
+    // (tools/probe_mfma_f64_4x4.hip).  Lists are a cluster's prototypes (20 .. 45 at C4), so a list's last tile
+    // is a quarter to three quarters empty more often than not.
+    auto run_step = [&](auto je_c, auto nq_c, const int st) {
+        constexpr int JE = decltype(je_c)::value, NQ = decltype(nq_c)::value;
+        static_assert(JE + (NQ > 0) <= JTL && JE + NQ >= 1 && NQ <= 3, "tiles of the step");
+        d4_t acc[JE > 0 ? JE : 1][IT];
+        double accq[NQ > 0 ? NQ : 1][IT];
+#pragma unroll
+        for (int u = 0; u < (NQ > 0 ? NQ : 1); ++u)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) accq[u][it] = 0.0;
 #pragma unroll
         for (int jt = 0; jt < JE; ++jt)
 #pragma unroll
@@ -2099,38 +2114,44 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (t + (NS - 1) < ntile) issue();
-            const char *stage = smem + r_stage;
+            const int a_st = r_stage + a_base, aq_st = r_stage + aq_base, b_st = r_stage + b_base;
             r_stage = (r_stage == (NS - 1) * S_STAGE) ? 0 : r_stage + S_STAGE;
-            // every fragment of the tile first, then the products
-            double a[KT / 4][JE];
-            std::conditional_t<sizeof(XT) == 4, float, double> braw[KT / 4][IT];
+            // every fragment of the tile first, then the products (8 wavefronts of 80 registers: two tiles + two or
+            // three groups in two halves, or the fragments spill inside the loop)
+            constexpr int KB = (NWV == 8 && sizeof(XT) == 4 && JE + NQ > 3) ? KT / 8 : KT / 4;
 #pragma unroll
-            for (int ks = 0; ks < KT / 4; ++ks) {
+            for (int k0 = 0; k0 < KT / 4; k0 += KB) {
+                double a[KB][JE > 0 ? JE : 1], aq[KB][NQ > 0 ? NQ : 1];
+                xfrag_t braw[KB][IT];
 #pragma unroll
-                for (int u = 0; u < JE; ++u) {
-                    const int ca = (2 * ks + (lq >> 1)) ^ a_swz[u];
-                    a[ks][u] = *reinterpret_cast<const double *>(stage + a_off[u] + ca * 16);
+                for (int kk = 0; kk < KB; ++kk) {
+                    const int ks = k0 + kk;
+#pragma unroll
+                    for (int u = 0; u < JE; ++u)
+                        a[kk][u] = *reinterpret_cast<const double *>(smem + (a_st ^ (32 * ks)) + u * 2048);
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u)   // chunk (2 ks + hq) ^ (2 u + (row >> 1)) = 2 (ks ^ u) ^ (hq ^ (row >> 1))
+                        aq[kk][u] = *reinterpret_cast<const double *>(smem + aq_st + (16 * JE + 4 * u) * 128 + 32 * (ks ^ u));
+#pragma unroll
+                    for (int u = 0; u < IT; ++u)
+                        braw[kk][u] = *reinterpret_cast<const xfrag_t *>(smem + (b_st ^ (B_KS * ks)) + u * B_TILE);
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < IT; ++u) {
-                    if constexpr (sizeof(XT) == 4) {
-                        const int cb = ks ^ b_swz[u];
-                        braw[ks][u] = *reinterpret_cast<const float *>(stage + b_off[u] + cb * 16);
-                    } else {
-                        const int cb = (2 * ks + (lq >> 1)) ^ b_swz[u];
-                        braw[ks][u] = *reinterpret_cast<const double *>(stage + b_off[u] + cb * 16);
-                    }
+                for (int kk = 0; kk < KB; ++kk) {
+#pragma unroll
+                    for (int jt = 0; jt < JE; ++jt)
+#pragma unroll
+                        for (int it = 0; it < IT; ++it)
+                            acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][jt], (double)braw[kk][it], acc[jt][it],
+                                                                               0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                        for (int it = 0; it < IT; ++it)
+                            accq[u][it] = __builtin_amdgcn_mfma_f64_4x4x4f64(aq[kk][u], (double)braw[kk][it], accq[u][it], 0, 0, 0);
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < KT / 4; ++ks) {
-#pragma unroll
-                for (int jt = 0; jt < JE; ++jt)
-#pragma unroll
-                    for (int it = 0; it < IT; ++it)
-                        acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks][jt], (double)braw[ks][it], acc[jt][it],
-                                                                           0, 0, 0);
+                if constexpr (KB < KT / 4) __builtin_amdgcn_sched_barrier(0);
             }
         }
         // list entries and |w|^2 of the lane's candidates, 4 at a time: loads first (clamped positions, no
@@ -2161,19 +2182,55 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
                 }
             }
         }
+        if constexpr (NQ > 0) {
+            // the groups: the lane's prototype is entry 4 u + (lane >> 4) behind the full tiles -- j still ascends
+            int jq[NQ];
+            double yq[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int pos = st * SJ + JE * 16 + 4 * u + lq;
+                jq[u] = (int)list[pos < cnt ? pos : cnt - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) yq[u] = ww[jq[u]];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const bool listed = st * SJ + JE * 16 + 4 * u + lq < cnt;
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    double rv = (xi[it] + (-2.0 * accq[u][it])) + yq[u];
+                    if (!(rv > 0.0)) rv = (rv != rv) ? rv : 0.0;
+                    best[it].push(listed ? rv : (double)INFINITY, jq[u]);
+                }
+            }
+        }
     };
     for (int st = 0; st < nstep; ++st) {
-        // (K = 2 walks whole steps: tiles behind the end of the list hold no entries and are not pushed)
-        const int left = (cnt - st * SJ + 15) / 16;
-        if constexpr (JTL == 1 || K != 1) {
-            run_step(std::integral_constant<int, JTL>{}, st);
-        } else if constexpr (JTL == 2) {
-            if (left == 1) run_step(std::integral_constant<int, 1>{}, st);
-            else run_step(std::integral_constant<int, 2>{}, st);
+        if constexpr (K != 1) {
+            // (k = 2 walks whole steps: tiles behind the end of the list hold no entries and are not pushed)
+            run_step(std::integral_constant<int, JTL>{}, std::integral_constant<int, 0>{}, st);
         } else {
-            if (left == 1) run_step(std::integral_constant<int, 1>{}, st);
-            else if (left == 2) run_step(std::integral_constant<int, 2>{}, st);
-            else run_step(std::integral_constant<int, 3>{}, st);
+            // the step's entries as full tiles + groups of four: a last tile with up to 12 entries goes as groups
+            int e = cnt - st * SJ;
+            e = e > SJ ? SJ : e;
+            const int tiles = (e + 15) / 16, rem = e - 16 * (tiles - 1);
+            const int full = rem <= 4 * QUAD_MAX ? tiles - 1 : tiles, nq = rem <= 4 * QUAD_MAX ? (rem + 3) / 4 : 0;
+#define DBGSOM_STEP(F, Q) run_step(std::integral_constant<int, F>{}, std::integral_constant<int, Q>{}, st)
+#define DBGSOM_STEP_Q(F)                                                                                  \
+            do {                                                                                          \
+                if (nq == 0) { if constexpr (F > 0) DBGSOM_STEP(F, 0); }                                  \
+                else if constexpr (F < JTL) {                                                             \
+                    if (nq == 1) DBGSOM_STEP(F, 1); else if (nq == 2) DBGSOM_STEP(F, 2); else DBGSOM_STEP(F, 3); \
+                }                                                                                         \
+            } while (0)
+            if (full == 0) DBGSOM_STEP_Q(0);
+            else if (full == 1) DBGSOM_STEP_Q(1);
+            else if constexpr (JTL >= 2) {
+                if (full == 2) DBGSOM_STEP_Q(2);
+                else if constexpr (JTL >= 3) DBGSOM_STEP_Q(3);
+            }
+#undef DBGSOM_STEP_Q
+#undef DBGSOM_STEP
         }
     }
 #pragma unroll
