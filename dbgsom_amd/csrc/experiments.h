@@ -31,3 +31,34 @@
 #define CSTAMP_LOADS_LANDED
 #define CSTAMP_FLUSH(dist, rows_s, n)
 #endif
+
+// ---- subset_exact_kernel (filter.hip) -----------------------------------------------------------------------
+// EXACT_TIMELINE=1: a workgroup's life in s_memrealtime ticks (100 MHz, one clock for all XCDs) and where it ran, carried as NEGATIVE distances
+// of its first six samples: -(1 + (class << 51 | workgroup << 33 | (value & 0x3fffffff) << 3 | field)), fields: start, end,
+// list length << 8 | class << 4, XCC << 16 | HW_ID, first tile landed, last distances pushed, s_memtime (shader clock) at start and end -- tools/exact_timeline.py.
+#ifndef EXACT_TIMELINE
+#define EXACT_TIMELINE 0
+#endif
+#if EXACT_TIMELINE
+#define XT_DECL uint64_t xt_v[8] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0, __builtin_amdgcn_s_memtime(), 0}
+#define XT_MARK(k) do { xt_v[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define XT_MARK_ONCE(k) do { if (xt_v[k] == 0) xt_v[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define XT_FLUSH(JTL_, cnt_, dist_, isamp0_, Kk_)                                                              \
+    do {                                                                                                       \
+        xt_v[7] = __builtin_amdgcn_s_memtime();                                                                \
+        xt_v[2] = ((uint64_t)(cnt_) << 8) | ((uint64_t)(JTL_) << 4);                                           \
+        xt_v[3] = ((uint64_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) |                                 \
+                  ((uint64_t)__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffff);                               \
+        if (wave == 0 && lq == 0 && lr < 8 && (isamp0_) >= 0) {                                                \
+            const uint64_t key_ = ((uint64_t)(JTL_) << 18) | (blockIdx.x & 0x3ffff);                           \
+            uint64_t val_ = xt_v[0];                                                                           \
+            for (int f_ = 1; f_ < 8; ++f_) if (lr == f_) val_ = xt_v[f_];                                      \
+            (dist_)[(isamp0_) * (Kk_)] = -(double)((key_ << 33) | ((val_ & 0x3fffffffull) << 3) | (uint64_t)lr) - 1.0; \
+        }                                                                                                      \
+    } while (0)
+#else
+#define XT_DECL
+#define XT_MARK(k)
+#define XT_MARK_ONCE(k)
+#define XT_FLUSH(JTL_, cnt_, dist_, isamp0_, Kk_)
+#endif

@@ -1941,6 +1941,15 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
 // NS = stages of the ring (NS - 1 tiles in flight).  3 where the chip is full of workgroups; the 64-sample
 // workgroups of a small sample set (one or two rounds of workgroups) take as many stages as fit four
 // workgroups per CU: 6 / 5 / 4 for JTL = 1 / 2 / 3 (C2 stage 99 -> 91 us, a 125 k-row share of C4 235 -> 212).
+// (in-kernel stamps of the experiment builds: csrc/experiments.h, tools/build_variant.sh; empty in the library)
+#ifdef DBGSOM_EXPERIMENTS
+#include "experiments.h"
+#else
+#define XT_DECL
+#define XT_MARK(k)
+#define XT_MARK_ONCE(k)
+#define XT_FLUSH(JTL_, cnt_, dist_, isamp0_, Kk_)
+#endif
 #ifndef DBGSOM_QUAD_MAX
 #define DBGSOM_QUAD_MAX 3
 #endif
@@ -1973,6 +1982,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
     const int wg = sched[range[0] + entry];
     const int cnt = (int)ucount[wg];
 
+    XT_DECL;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 4 waves x 32 samples
@@ -1981,13 +1991,16 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
     if (p0 >= N) return;  // (the second half of a last, partial bucket)
     const uint16_t *list = ulist + (size_t)wg * ulist_stride;
 
+    // Set-up: a workgroup lives ~35 us at C3 and its first tile used to land after 6 -- four dependent round
+    // trips (schedule -> sample ids -> |x|^2 -> list entries -> DMA).  Everything that depends on the bucket alone
+    // (the sample ids of the lane's results and of its DMA rows, the first step's list entries) is loaded in ONE
+    // round trip, the first tiles' DMAs follow, and |x|^2 -- needed behind the first step only -- comes last.
     double xi[IT];
     int64_t isamp[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int64_t p = p0 + wave * WS + it * 16 + lr;
-        isamp[it] = (p < N) ? order[p] : -1;
-        xi[it] = (p < N) ? xx[isamp[it]] : 0.0;
+        isamp[it] = order[p < N ? p : N - 1];
     }
     Best<K> best[IT];
 #pragma unroll
@@ -1996,14 +2009,11 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
     // DMA sources. X tile: 8 (f32) / 16 (f64) instructions, wave w issues q = XD w .. XD w + XD - 1
     // = the rows of its own 32 samples
     const XT *xsrc[XD];
+    int xrow[XD];
 #pragma unroll
     for (int u = 0; u < XD; ++u) {
-        const int L = 64 * (XD * wave + u) + lane;
-        const int r = L / XCH, cp = L % XCH;
-        const int c = cp ^ ((r >> 1) & (XCH - 1));
-        int64_t p = p0 + r;
-        p = p < N ? p : N - 1;
-        xsrc[u] = X + (int64_t)order[p] * ldx + c * (16 / (int)sizeof(XT));
+        int64_t p = p0 + (64 * (XD * wave + u) + lane) / XCH;
+        xrow[u] = order[p < N ? p : N - 1];
     }
     // W tile: SJ rows x 128 B = 2 JTL instructions (8 rows each), issued by waves 0 .. 2 JTL - 1
     // (JTL = 3: waves 0, 1 take two)
@@ -2014,6 +2024,20 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
     const int wq0 = NWV == 8 ? wave
                              : ((wave < W_INSTR - 4) ? 2 * wave : (W_INSTR > 4 ? wave + (W_INSTR - 4) : wave));
     const int wlr = lane >> 3, wcp = lane & 7;
+    int wfirst[2] = {0, 0};   // (the first step's list entries of the lane's W rows)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (u < n_wdma) {
+            const int pos = 8 * (wq0 + u) + wlr;
+            wfirst[u] = (int)list[pos < cnt ? pos : cnt - 1];
+        }
+#pragma unroll
+    for (int u = 0; u < XD; ++u) {
+        const int L = 64 * (XD * wave + u) + lane;
+        const int r = L / XCH, cp = L % XCH;
+        const int c = cp ^ ((r >> 1) & (XCH - 1));
+        xsrc[u] = X + (int64_t)xrow[u] * ldx + c * (16 / (int)sizeof(XT));
+    }
 
     const int nkt = d / KT;
     const int nstep = (cnt + SJ - 1) / SJ;
@@ -2024,8 +2048,14 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
     // ring (vmcnt counts in order) each tile.
     int i_kt = 0, i_step = 0, i_stage = 0;
     const double *wrow[2] = {W, W};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (u < n_wdma) {
+            const int wr = 8 * (wq0 + u) + wlr;
+            wrow[u] = W + (int64_t)wfirst[u] * d + (wcp ^ ((wr >> 1) & 7)) * 2;
+        }
     auto issue = [&]() {
-        if (i_kt == 0) {
+        if (i_kt == 0 && i_step > 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (u < n_wdma) {
@@ -2066,6 +2096,11 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
         if (ntile > u) issue();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        xi[it] = xx[isamp[it]];
+        if (p0 + wave * WS + it * 16 + lr >= N) isamp[it] = -1;   // (a last, partial bucket: nothing stored)
+    }
     int t = 0, r_stage = 0;
     // One step of the list: its nkt k-tiles on the first JE 16-prototype tiles, then the candidates' distances.
     // JE is a compile-time figure -- the last step of a list is short (65 entries in 48-entry steps: 48 + 17, two
@@ -2113,6 +2148,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            XT_MARK_ONCE(4);   // (the first tile has landed)
             if (t + (NS - 1) < ntile) issue();
             const int a_st = r_stage + a_base, aq_st = r_stage + aq_base, b_st = r_stage + b_base;
             r_stage = (r_stage == (NS - 1) * S_STAGE) ? 0 : r_stage + S_STAGE;
@@ -2233,6 +2269,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
 #undef DBGSOM_STEP
         }
     }
+    XT_MARK(5);   // (the last step's distances are pushed)
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
 #pragma unroll
@@ -2256,6 +2293,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
             }
         }
     }
+    XT_MARK(1);
+    XT_FLUSH(JTL, cnt, dist_out, isamp[0], K);
 }
 
 #include "refine.h"
