@@ -290,13 +290,21 @@ def parity_gate(X, W0, hop, sigma, gamma, info, Wn_hip, xbytes):
 def list_flops(counts, n, d):
     """(useful, executed) float64 flops of the exact-on-candidates stage from the candidate-list
     lengths: a 128-sample workgroup evaluates its list in steps of 16 / 32 / 48 prototypes
-    (classes <= 16, 17..32, > 32), every row of the workgroup against every listed prototype."""
+    (classes <= 16, 17..32, > 32), every row of the workgroup against every listed prototype.
+    Executed: per step whole 16-prototype tiles (v_mfma_f64_16x16x4), a last tile with up to 12 entries as
+    groups of four (v_mfma_f64_4x4x4: a quarter of a tile's matrix time per group) -- filter.hip,
+    subset_exact_kernel."""
     counts = counts.astype(np.float64)
     rows = np.full(counts.shape, 128.0)
     if n % 128:
         rows[-1] = n % 128
     step = np.where(counts <= 16, 16.0, np.where(counts <= 32, 32.0, 48.0))
-    padded = np.ceil(counts / step) * step
+    whole = np.floor(counts / step)                      # full steps
+    last = counts - whole * step                         # entries of the last, partial step (0: none)
+    tiles = np.ceil(last / 16.0)
+    rem = last - 16.0 * np.maximum(tiles - 1.0, 0.0)
+    last_exec = np.where(last > 0, np.where(rem <= 12, 16.0 * (tiles - 1.0) + 4.0 * np.ceil(rem / 4.0), 16.0 * tiles), 0.0)
+    padded = whole * step + last_exec
     return float((2.0 * rows * counts * d).sum()), float((2.0 * 128.0 * padded * d).sum())
 
 
