@@ -1549,3 +1549,64 @@ np.savez(sys.argv[1], **{f"{k[0]}_{k[1]}_{k[2]}_W": v[0] for k, v in out.items()
         assert sorted(a.files) == sorted(b.files) and len(a.files) == 12
         for k in a.files:
             assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def _step_shapes(counts):
+    """(class, whole tiles, groups of four) of every step the exact stage takes for lists of these lengths
+    (filter.hip, subset_exact_kernel: 16 / 32 / 48-entry steps; a last tile with up to 12 entries as groups)."""
+    out = set()
+    for c in np.unique(counts):
+        c = int(c)
+        cls = 1 if c <= 16 else (2 if c <= 32 else 3)
+        sj, left = 16 * cls, c
+        while left > 0:
+            e = min(sj, left)
+            tiles = (e + 15) // 16
+            rem = e - 16 * (tiles - 1)
+            out.add((cls, tiles - 1, (rem + 3) // 4) if rem <= 12 else (cls, tiles, 0))
+            left -= e
+    return out
+
+
+@pytest.mark.parametrize("dtype,repeat,algo_opts", [(np.float32, 1, {}), (np.float32, 10, {}), (np.float64, 1, {}),
+                                                    (np.float32, 1, {"refine": 1})])
+def test_exact_stage_every_count_of_tiles_and_groups(o, dtype, repeat, algo_opts):
+    """Lists of every length from 1 to 110: cluster c of the map is c + 1 nearly coincident prototypes, its samples
+    (whole 128-sample buckets, seeded by their winners) can rule none of them out.  The exact stage then takes steps
+    of every shape -- whole 16-prototype tiles x groups of four in each list-length class, the 64-sample workgroups
+    of small sample sets (repeat = 1) and the 128-sample ones (repeat = 10: more than 1024 buckets) -- and winners
+    and distances must be those of the all-pairs kernel bit for bit, and of the oracle's chain on a sample."""
+    from dbgsom_amd.backend import HipBackend
+
+    rng = np.random.default_rng(77)
+    d, C = 32, 110
+    centres = rng.normal(size=(C, d)) * 40.0
+    mult = np.arange(1, C + 1)
+    W = np.concatenate([centres[c] + rng.normal(size=(mult[c], d)) * 1e-6 for c in range(C)]).astype(np.float64)
+    W[5] = W[4]                                        # (an exact duplicate inside a group of four: the lower index wins)
+    M = W.shape[0]
+    X = np.concatenate([centres[c] + rng.normal(size=(128 * repeat, d)) * 0.5 for c in range(C)]).astype(dtype)
+    N = X.shape[0]
+    ex = HipBackend(algorithm="exact").load(X)
+    de, ie = ex.bmu(W, 1)
+    fi = HipBackend(algorithm="filtered_hint").load(X)
+    fi.sweep_planes = 4                                # candidates from the triangle inequality
+    for k_, v_ in algo_opts.items():
+        setattr(fi, k_, v_)
+    fi.set_hint(ie, M)
+    df, jf = fi.bmu(W, 1)
+    assert np.array_equal(jf, ie) and np.array_equal(df, de)
+    counts = fi.filter_counts()
+    shapes = _step_shapes(counts)
+    if not algo_opts:
+        want = {(1, 0, 1), (1, 0, 2), (1, 0, 3), (1, 1, 0)} | {(2, 1, q) for q in (1, 2, 3)} | {(2, 2, 0)} | \
+               {(3, f, q) for f in range(3) for q in range(4) if f + q} | {(3, 3, 0)}
+        assert want <= shapes, sorted(want - shapes)
+    pick = rng.choice(N, 1500, replace=False)
+    rd, ri = o.bmu_chain(X[pick].astype(np.float32 if dtype == np.float32 else np.float64), W, 1)
+    assert np.array_equal(jf[pick], ri) and np.array_equal(df[pick], rd)
+    # the two nearest (k = 2 walks whole tiles) on the same lists
+    d2, j2 = fi.bmu(W, 2)
+    e2, i2 = ex.bmu(W, 2)
+    assert np.array_equal(j2, i2) and np.array_equal(d2, e2)
+    ex.release(); fi.release()
