@@ -1954,8 +1954,19 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
 #define DBGSOM_QUAD_MAX 3
 #endif
 constexpr int QUAD_MAX = DBGSOM_QUAD_MAX;   // a last tile with up to 4 QUAD_MAX entries goes as groups of four
+// (stages of the 64-sample workgroups' ring: what fits four workgroups per CU, 40 KB each)
+constexpr int split_ring_stages(int jtl, int xs) {
+    const int n = (40 * 1024) / (64 * 16 * xs + jtl * 16 * 16 * 8);
+    return n > 6 ? 6 : (n < 3 ? 3 : n);
+}
+template <typename XT, int JTL, int SPLIT, int NS>
+constexpr int subset_exact_lds_bytes() { return NS * ((128 / SPLIT) * KT * (int)sizeof(XT) + 16 * JTL * KT * 8); }
+
+// The stage's workgroup: `block` of its class's launch (or of its class's slice of a launch that holds all three
+// classes), `smem` the launch's one LDS object.
 template <typename XT, int JTL, int NWV, int SPLIT = 1, int K = 1, int NS = 3>
-__global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) void subset_exact_kernel(
+__device__ __forceinline__ void subset_exact_workgroup(
+    char *__restrict__ smem, const unsigned block,
     const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
     const double *__restrict__ W, int M, const double *__restrict__ ww,
     const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
@@ -1974,10 +1985,10 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
     constexpr int XROW = KT * (int)sizeof(XT), XCH = XROW / 16, XD = RW * XROW / 1024 / NWV;
     constexpr int S_XT = RW * XROW, S_WT = SJ * KT * 8, S_STAGE = S_XT + S_WT;  // 8 / 16 KB (SPLIT: half) + 2 JTL KB
     static_assert(NS >= 3 && NS <= 8, "3 .. 8 stages");
-    __shared__ __attribute__((aligned(16))) char smem[NS * S_STAGE];
-    // this class's slice of the schedule (2b): entry blockIdx.x of it, nothing beyond its end
+    static_assert(NS * S_STAGE == subset_exact_lds_bytes<XT, JTL, SPLIT, NS>(), "the launch's LDS object");
+    // this class's slice of the schedule (2b): entry `block` of it, nothing beyond its end
     const uint32_t *range = sched_range + 2 * (3 - JTL);
-    const unsigned entry = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
+    const unsigned entry = block / SPLIT, part = block % SPLIT;
     if (entry >= range[1]) return;
     const int wg = sched[range[0] + entry];
     const int cnt = (int)ucount[wg];
@@ -2295,6 +2306,47 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) vo
     }
     XT_MARK(1);
     XT_FLUSH(JTL, cnt, dist_out, isamp[0], K);
+}
+
+template <typename XT, int JTL, int NWV, int SPLIT = 1, int K = 1, int NS = 3>
+__global__ __launch_bounds__(NWV * 64, (NWV == 8 && sizeof(XT) == 4) ? 6 : 4) void subset_exact_kernel(
+    const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
+    const double *__restrict__ W, int M, const double *__restrict__ ww,
+    const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
+    const uint32_t *__restrict__ ucount, const int32_t *__restrict__ sched,
+    const uint32_t *__restrict__ sched_range, int round_f32, int64_t *__restrict__ idx_out,
+    double *__restrict__ dist_out) {
+    __shared__ __attribute__((aligned(16))) char smem[subset_exact_lds_bytes<XT, JTL, SPLIT, NS>()];
+    subset_exact_workgroup<XT, JTL, NWV, SPLIT, K, NS>(smem, blockIdx.x, X, N, d, ldx, xx, W, M, ww, order, ulist, ulist_stride,
+                                                       ucount, sched, sched_range, round_f32, idx_out, dist_out);
+}
+
+// Few sample buckets (one or two rounds of workgroups: C2, a rank's share): the three list-length classes of the
+// 64-sample workgroups in ONE launch, class by class along blockIdx.y (long lists are dispatched first) -- the same
+// workgroups as three launches on three streams, without the fork and the join of the streams (13 + 16 us of a
+// 0.4 ms epoch).  One block shape (4 wavefronts), one LDS size (40 KB: every class's ring is as deep as fits).
+template <typename XT>
+__global__ __launch_bounds__(256, 4) void subset_exact_split_kernel(
+    const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
+    const double *__restrict__ W, int M, const double *__restrict__ ww,
+    const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
+    const uint32_t *__restrict__ ucount, const int32_t *__restrict__ sched,
+    const uint32_t *__restrict__ sched_range, int round_f32, int64_t *__restrict__ idx_out,
+    double *__restrict__ dist_out) {
+    constexpr int XS = (int)sizeof(XT);
+    constexpr int NS3 = split_ring_stages(3, XS), NS2 = split_ring_stages(2, XS), NS1 = split_ring_stages(1, XS);
+    constexpr int B3 = subset_exact_lds_bytes<XT, 3, 2, NS3>(), B2 = subset_exact_lds_bytes<XT, 2, 2, NS2>(),
+                  B1 = subset_exact_lds_bytes<XT, 1, 2, NS1>();
+    __shared__ __attribute__((aligned(16))) char smem[B3 > B2 ? (B3 > B1 ? B3 : B1) : (B2 > B1 ? B2 : B1)];
+    if (blockIdx.y == 0)
+        subset_exact_workgroup<XT, 3, 4, 2, 1, NS3>(smem, blockIdx.x, X, N, d, ldx, xx, W, M, ww, order, ulist, ulist_stride,
+                                                    ucount, sched, sched_range, round_f32, idx_out, dist_out);
+    else if (blockIdx.y == 1)
+        subset_exact_workgroup<XT, 2, 4, 2, 1, NS2>(smem, blockIdx.x, X, N, d, ldx, xx, W, M, ww, order, ulist, ulist_stride,
+                                                    ucount, sched, sched_range, round_f32, idx_out, dist_out);
+    else
+        subset_exact_workgroup<XT, 1, 4, 2, 1, NS1>(smem, blockIdx.x, X, N, d, ldx, xx, W, M, ww, order, ulist, ulist_stride,
+                                                    ucount, sched, sched_range, round_f32, idx_out, dist_out);
 }
 
 #include "refine.h"
@@ -2755,7 +2807,22 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         const char *e = getenv("DBGSOM_EXACT_FORK");
         return e ? atoi(e) : 1;
     }();
-    const bool fork = fork_env != 0 && side.ready();
+    // few sample buckets (C2, a rank's share in strong scaling): two 64-sample workgroups per bucket
+    // (DBGSOM_EXACT_SPLIT=0|1 forces).  Measured at C2 (469 buckets): stage 0.164 -> see DESIGN.md
+    static const int split_env = [] {
+        const char *e = getenv("DBGSOM_EXACT_SPLIT");
+        return e ? atoi(e) : -1;
+    }();
+    // (with the refinement: what is left to this stage is a few workgroups)
+    const bool exact_split = split_env >= 0 ? split_env != 0 : (refine || f.nb <= 1024);
+    // (the 64-sample workgroups of all three classes go as one launch on the caller's stream: nothing to fork;
+    //  DBGSOM_EXACT_MERGED=0: three launches on three streams)
+    static const bool merged_env = [] {
+        const char *e = getenv("DBGSOM_EXACT_MERGED");
+        return e ? atoi(e) != 0 : true;
+    }();
+    const bool merged = merged_env && exact_split && !k2 && !refine;
+    const bool fork = fork_env != 0 && !merged && side.ready();
     hipStream_t s2 = fork ? side.stream : s, s3 = fork ? side.stream2 : s;
     // With the refinement the matrix-core stage only has the workgroups the refinement does not take (lists
     // beyond its tiles: a few long chains on a mostly idle chip): all of it on the second stream, beside the
@@ -2830,7 +2897,7 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
                                idx_dev, dist_dev);
     }
     // (stages of the 64-sample workgroups' ring: what fits four workgroups per CU, 40 KB each)
-#define SPLIT_NS(JTL, XS) ((40 * 1024) / (64 * 16 * (XS) + (JTL) * 16 * 16 * 8) > 6 ? 6 : ((40 * 1024) / (64 * 16 * (XS) + (JTL) * 16 * 16 * 8) < 3 ? 3 : (40 * 1024) / (64 * 16 * (XS) + (JTL) * 16 * 16 * 8)))
+#define SPLIT_NS(JTL, XS) split_ring_stages(JTL, XS)
 #define DBGSOM_SUBSET_W(JTL, NWV_, STREAM)                                                        \
     do {                                                                                          \
         if (exact_split && x_dtype == DBGSOM_F32)                                                 \
@@ -2858,14 +2925,6 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         const char *e = getenv("DBGSOM_EXACT_WAVES");
         return e ? atoi(e) : 84;
     }();
-    // few sample buckets (C2, a rank's share in strong scaling): two 64-sample workgroups per bucket
-    // (DBGSOM_EXACT_SPLIT=0|1 forces).  Measured at C2 (469 buckets): stage 0.164 -> see DESIGN.md
-    static const int split_env = [] {
-        const char *e = getenv("DBGSOM_EXACT_SPLIT");
-        return e ? atoi(e) : -1;
-    }();
-    // (with the refinement: what is left to this stage is a few workgroups)
-    const bool exact_split = split_env >= 0 ? split_env != 0 : (refine || f.nb <= 1024);
     // (two digits: class 3, then classes 2 and 1)
 #define DBGSOM_SUBSET(JTL, STREAM)                                                                \
     do {                                                                                          \
@@ -2892,6 +2951,15 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         DBGSOM_SUBSET_K2(2, s2);
         DBGSOM_SUBSET_K2(1, s3);
 #undef DBGSOM_SUBSET_K2
+    } else if (merged) {
+        if (x_dtype == DBGSOM_F32)
+            hipLaunchKernelGGL((subset_exact_split_kernel<float>), dim3((unsigned)(2 * f.nb), 3), dim3(256), 0, s,
+                               (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev, f.ulist,
+                               (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev);
+        else
+            hipLaunchKernelGGL((subset_exact_split_kernel<double>), dim3((unsigned)(2 * f.nb), 3), dim3(256), 0, s,
+                               (const double *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev, f.ulist,
+                               (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev);
     } else {
         DBGSOM_SUBSET(3, s_mfma);
         DBGSOM_SUBSET(2, refine ? s3 : s2);
