@@ -2349,6 +2349,38 @@ __global__ __launch_bounds__(256, 4) void subset_exact_split_kernel(
                                                     ucount, sched, sched_range, round_f32, idx_out, dist_out);
 }
 
+// The same for many sample buckets: the 128-sample workgroups of all three classes in one launch, every class as
+// 8 wavefronts x 16 samples with the long-list class's LDS size (three workgroups per CU whatever the class: a slot
+// that a workgroup leaves fits any other, and the dispatch order IS the schedule's -- long lists first, the short
+// ones at the end of the stage).  Against three launches side by side (4 x 32 samples for the two short classes,
+// measured the better shape for them): C4 stage 1.036 -> 1.027 ms, epoch 2.220 -> 2.190; C3 0.401 -> 0.381 / 0.998 -> 0.977.
+template <typename XT>
+__global__ __launch_bounds__(512, sizeof(XT) == 4 ? 6 : 4) void subset_exact_all_kernel(
+    const XT *__restrict__ X, int64_t N, int d, int64_t ldx, const double *__restrict__ xx,
+    const double *__restrict__ W, int M, const double *__restrict__ ww,
+    const int32_t *__restrict__ order, const uint16_t *__restrict__ ulist, int ulist_stride,
+    const uint32_t *__restrict__ ucount, const int32_t *__restrict__ sched,
+    const uint32_t *__restrict__ sched_range, int round_f32, int64_t *__restrict__ idx_out,
+    double *__restrict__ dist_out) {
+    __shared__ __attribute__((aligned(16))) char smem[subset_exact_lds_bytes<XT, 3, 1, 3>()];
+    // Launch order = dispatch order = the schedule's: long lists first, the short ones at the end of the stage.
+    // (The long-list and the middle class ALTERNATING while both last -- one alone asks for all of the matrix pipe,
+    //  the other for three quarters of it -- was measured: C4 stage 1.09 -> 1.21 ms.)
+    const unsigned n3 = sched_range[1], n2 = sched_range[3], n1 = sched_range[5];
+    const unsigned b = blockIdx.x;
+    if (b >= n3 + n2 + n1) return;
+    const unsigned cls = b < n3 ? 3u : (b < n3 + n2 ? 2u : 1u), e = b < n3 ? b : (b < n3 + n2 ? b - n3 : b - n3 - n2);
+    if (cls == 3u)
+        subset_exact_workgroup<XT, 3, 8, 1, 1, 3>(smem, e, X, N, d, ldx, xx, W, M, ww, order, ulist, ulist_stride,
+                                                  ucount, sched, sched_range, round_f32, idx_out, dist_out);
+    else if (cls == 2u)
+        subset_exact_workgroup<XT, 2, 8, 1, 1, 3>(smem, e, X, N, d, ldx, xx, W, M, ww, order, ulist, ulist_stride,
+                                                  ucount, sched, sched_range, round_f32, idx_out, dist_out);
+    else
+        subset_exact_workgroup<XT, 1, 8, 1, 1, 3>(smem, e, X, N, d, ldx, xx, W, M, ww, order, ulist, ulist_stride,
+                                                  ucount, sched, sched_range, round_f32, idx_out, dist_out);
+}
+
 #include "refine.h"
 
 // ---- launchers ----------------------------------------------------------------------------------
@@ -2815,13 +2847,13 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
     }();
     // (with the refinement: what is left to this stage is a few workgroups)
     const bool exact_split = split_env >= 0 ? split_env != 0 : (refine || f.nb <= 1024);
-    // (the 64-sample workgroups of all three classes go as one launch on the caller's stream: nothing to fork;
-    //  DBGSOM_EXACT_MERGED=0: three launches on three streams)
+    // (k = 1 without the refinement: all three list-length classes go as ONE launch on the caller's stream -- nothing
+    //  to fork; DBGSOM_EXACT_MERGED=0: three launches on three streams)
     static const bool merged_env = [] {
         const char *e = getenv("DBGSOM_EXACT_MERGED");
         return e ? atoi(e) != 0 : true;
     }();
-    const bool merged = merged_env && exact_split && !k2 && !refine;
+    const bool merged = merged_env && !k2 && !refine;
     const bool fork = fork_env != 0 && !merged && side.ready();
     hipStream_t s2 = fork ? side.stream : s, s3 = fork ? side.stream2 : s;
     // With the refinement the matrix-core stage only has the workgroups the refinement does not take (lists
@@ -2951,6 +2983,15 @@ int dbgsom::launch_bmu_filtered(const FilteredCall &call) {
         DBGSOM_SUBSET_K2(2, s2);
         DBGSOM_SUBSET_K2(1, s3);
 #undef DBGSOM_SUBSET_K2
+    } else if (merged && !exact_split) {
+        if (x_dtype == DBGSOM_F32)
+            hipLaunchKernelGGL((subset_exact_all_kernel<float>), dim3((unsigned)f.nb), dim3(512), 0, s,
+                               (const float *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev, f.ulist,
+                               (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev);
+        else
+            hipLaunchKernelGGL((subset_exact_all_kernel<double>), dim3((unsigned)f.nb), dim3(512), 0, s,
+                               (const double *)X_dev, N, (int)d, ldx, xx_dev, W_dev, (int)M, ww_dev, order_dev, f.ulist,
+                               (int)f.Mpad, f.ucount, f.sched, f.sched_ctr + 2 * SCHED_BINS, round_f32, idx_dev, dist_dev);
     } else if (merged) {
         if (x_dtype == DBGSOM_F32)
             hipLaunchKernelGGL((subset_exact_split_kernel<float>), dim3((unsigned)(2 * f.nb), 3), dim3(256), 0, s,
