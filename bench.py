@@ -347,7 +347,7 @@ def rooflines(workload, n, d, M, xbytes, ph, planes, counts, refined=False):
         useful, padded = list_flops(counts, n, d)
         t = ph["exact_on_candidates"] * 1e-3
         traffic, src = measured_traffic(workload, "subset_exact")
-        out.append({"stage": "exact search on candidates", "kernel": "subset_exact_kernel (3 list-length classes)",
+        out.append({"stage": "exact search on candidates", "kernel": "subset_exact_all_kernel / subset_exact_split_kernel (3 list-length classes, one launch)",
                     "bound": "mfma", "dtype": "f64", "achieved": useful / t / 1e12,
                     "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": useful / t / 1e12 / F64_MFMA_PEAK_TFLOPS,

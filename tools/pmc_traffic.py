@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-KEYS = {"sweep": "sweep4_i8_kernel<0", "prepass": "sweep4_i8_kernel<1", "subset_exact": "subset_exact_kernel",
+KEYS = {"sweep": "sweep4_i8_kernel<0", "prepass": "sweep4_i8_kernel<1", "subset_exact": "subset_exact_",
         "segsum": "segsum_kernel", "bmu_dma": "bmu_dma_kernel", "smooth_gemm": "smooth_gemm_kernel",
         "prune": "prune_mark_kernel", "proto_gap": "proto_gap_kernel", "refine": "refine_i8_kernel",
         "pair_exact": "pair_exact_kernel"}
