@@ -1934,10 +1934,11 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
 
 // ---- 3. exact arg-min over the marked prototypes (float64 MFMA on gathered rows) -----------------
 // 128 gathered samples x SJ = 16 JTL listed prototypes per step; 4 wavefronts x 32 samples or 8 x 16
-// (NWV), 3-stage LDS-DMA ring.  Three instantiations (JTL = 1, 2, 3) are launched back to back, each
-// takes the workgroups whose list length falls in its class (<= 16, 17..32, > 32) so that the
-// gathered X tile is streamed once for all but the longest lists (a fourth class of 64 was
-// measured: no gain at C3 / C4, slower at C2).
+// (NWV), 3-stage LDS-DMA ring.  Three instantiations (JTL = 1, 2, 3), each for the workgroups whose list
+// length falls in its class (<= 16, 17..32, > 32) so that the gathered X tile is streamed once for all
+// but the longest lists (a fourth class of 64 was measured: no gain at C3 / C4, slower at C2): as one
+// launch (subset_exact_all_kernel / subset_exact_split_kernel, behind the workgroup's body) or, k = 2 and
+// beside the refinement, as three launches on three streams (subset_exact_kernel).
 // NS = stages of the ring (NS - 1 tiles in flight).  3 where the chip is full of workgroups; the 64-sample
 // workgroups of a small sample set (one or two rounds of workgroups) take as many stages as fit four
 // workgroups per CU: 6 / 5 / 4 for JTL = 1 / 2 / 3 (C2 stage 99 -> 91 us, a 125 k-row share of C4 235 -> 212).

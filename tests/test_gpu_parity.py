@@ -1571,7 +1571,7 @@ def _step_shapes(counts):
 
 
 @pytest.mark.parametrize("dtype,repeat,algo_opts", [(np.float32, 1, {}), (np.float32, 10, {}), (np.float64, 1, {}),
-                                                    (np.float32, 1, {"refine": 1})])
+                                                    (np.float64, 10, {}), (np.float32, 1, {"refine": 1})])
 def test_exact_stage_every_count_of_tiles_and_groups(o, dtype, repeat, algo_opts):
     """Lists of every length from 1 to 110: cluster c of the map is c + 1 nearly coincident prototypes, its samples
     (whole 128-sample buckets, seeded by their winners) can rule none of them out.  The exact stage then takes steps
