@@ -1798,17 +1798,28 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
                         awr[rh + r] = __builtin_amdgcn_sdot4(wv[r][u][e], wv[r][u][e], awr[rh + r], false);
                     }
         }
+    // The thread's four samples' sums over the sample's eight lanes (every lane ends up with the totals), then ONE pass
+    // of the float64 bound with lane q of the eight taking sample q -- four passes with one lane in eight at work were
+    // half of the instructions this kernel issues at d = 128.
 #pragma unroll
     for (int round = 0; round < 4; ++round) {
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+            a0r[round] += __shfl_xor(a0r[round], m, 64);
+            axr[round] += __shfl_xor(axr[round], m, 64);
+            awr[round] += __shfl_xor(awr[round], m, 64);
+        }
+    }
+    {
+        const int round = q & 3;
         const int il = round * 32 + (tid >> 3);
         const int pj = prev_s[il];
         const int64_t i = samp_s[il];
-        int a0 = a0r[round], ax = axr[round], aw = awr[round];
-#pragma unroll
-        for (int m = 1; m < 8; m <<= 1) {
-            a0 += __shfl_xor(a0, m, 64); ax += __shfl_xor(ax, m, 64); aw += __shfl_xor(aw, m, 64);
-        }
-        if (q == 0 && pj != -2) {
+        const int a0 = round == 0 ? a0r[0] : (round == 1 ? a0r[1] : (round == 2 ? a0r[2] : a0r[3]));
+        const int ax = round == 0 ? axr[0] : (round == 1 ? axr[1] : (round == 2 ? axr[2] : axr[3]));
+        const int aw = round == 0 ? awr[0] : (round == 1 ? awr[1] : (round == 2 ? awr[2] : awr[3]));
+        const double hint = round == 0 ? hint_up[0] : (round == 1 ? hint_up[1] : (round == 2 ? hint_up[2] : hint_up[3]));
+        if (q < 4 && pj != -2) {
             unsigned long long bits = INF_BITS;
             if (pj >= 0) {
                 const double sv = sx[i], tv = tw[pj];
@@ -1816,8 +1827,8 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
                 const double dh2 = ((sq - cr) + 1e-12 * (sq + fabs(cr))) / 16129.0;
                 // (|x_i|^2 or |w_seed|^2 not finite -- a NaN or an infinity in the row: rho is not, and no bound)
                 const double rho = 4.0 * (double)(d + 16) * 1.1102230246251565e-16 * (xx[i] + yy_max) + 0.0 * ww[pj];
-                const double up = hint_up[round] >= 0.0
-                                      ? hint_up[round] + sqrt(rho) * (1.0 + 1e-12)
+                const double up = hint >= 0.0
+                                      ? hint + sqrt(rho) * (1.0 + 1e-12)
                                       : (dh2 > 0.0 ? sqrt(dh2) * (1.0 + 1e-12) : 0.0) + root_d * (sv + tv) * PLANE0_ERR;
                 if (fabs(up) < INFINITY) {  // (a NaN fails this too)
                     const double nn = nnub ? (double)__uint_as_float(nnub[pj]) : 0.0;  // (+inf: no bound, the whole map)
