@@ -62,3 +62,16 @@
 #define XT_MARK_ONCE(k)
 #define XT_FLUSH(JTL_, cnt_, dist_, isamp0_, Kk_)
 #endif
+
+// ---- prune_mark_kernel (filter.hip) -------------------------------------------------------------------------
+// PRUNE_STAMPS=1: s_memrealtime (100 MHz) of thread 0 at the kernel's phase boundaries, 8 values per workgroup in
+// a device array; dbgsom_experiment_prune_stamps() copies it out (tools/prune_timeline.py).
+#ifndef PRUNE_STAMPS
+#define PRUNE_STAMPS 0
+#endif
+#if PRUNE_STAMPS
+__device__ unsigned long long g_prune_stamps[8 * 16384];
+#define PM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_prune_stamps[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PM_STAMP(k)
+#endif

@@ -25,6 +25,17 @@
 
 #include "bmu_common.h"
 
+// (in-kernel stamps of the experiment builds: csrc/experiments.h, tools/build_variant.sh; empty in the library)
+#ifdef DBGSOM_EXPERIMENTS
+#include "experiments.h"
+#else
+#define PM_STAMP(k)
+#define XT_DECL
+#define XT_MARK(k)
+#define XT_MARK_ONCE(k)
+#define XT_FLUSH(JTL_, cnt_, dist_, isamp0_, Kk_)
+#endif
+
 namespace dbgsom {
 
 constexpr double FQ = 8323072.0;  // 127 * 2^16
@@ -1721,6 +1732,7 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
         group = retry_groups[blockIdx.x];
     }
     const int64_t p0 = group * 128;
+    PM_STAMP(0);
     const int nwords = (M + 31) / 32;
     const unsigned long long INF_BITS = 0x7ff0000000000000ull;
     for (int w = tid; w < nwords; w += 256) mask[w] = 0u;
@@ -1739,6 +1751,7 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
     }
     if (tid == 0) misc[0] = 0;  // 1: some sample has no bound -- every prototype is a candidate
     __syncthreads();
+    PM_STAMP(1);   // (sample ids and seeds are here)
     // |x_i - w_seed|^2 from one digit product: 8 threads per sample, 16 bytes of the row each per step
     const double yy_max = summary[2], root_d = sqrt((double)d) * (1.0 + 1e-12);
     // (the four samples of a thread side by side, two 16-byte steps each: 16 loads in flight -- one
@@ -1746,7 +1759,7 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
     const int q = tid & 7, nch = dpad / 16;
     int a0r[4] = {0, 0, 0, 0}, axr[4] = {0, 0, 0, 0}, awr[4] = {0, 0, 0, 0};  // P, A, B of the header
     const int8_t *xrow[4], *wrow[4];
-    int wswz[4];
+    int wswz[4], xodd = 0;   // (bit r: sample r's row starts in the middle of a cache line)
     bool live[4];
     double hint_up[4];  // >= 0: the seed distance is known without the sample's row (see below)
 #pragma unroll
@@ -1766,6 +1779,11 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
         }
         live[r] = pj >= 0 && !(hint_up[r] >= 0.0);
         xrow[r] = xplanes + (size_t)samp_s[il] * dpad;
+        // (a row whose pitch is an odd number of 64-byte halves starts in the middle of a cache line every other
+        //  sample: its eight lanes then walk the row in 128-byte windows that ARE lines -- the first window half
+        //  empty -- instead of straddling two lines with every load; read once and non-temporal, a straddled line
+        //  came from memory twice: 1.43 GB for 0.83 GB of plane at d = 784)
+        xodd |= (int)((((size_t)samp_s[il] * (size_t)dpad) >> 6) & 1) << r;
         wrow[r] = wplanes + (size_t)(live[r] ? pj : 0) * FKT;
         wswz[r] = live[r] ? (pj >> 2) & 3 : 0;
     }
@@ -1773,14 +1791,14 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
     //  kernel -- eight workgroups per CU instead of four share the latency of its ~8 dependent steps)
 #pragma unroll
     for (int rh = 0; rh < 4; rh += 2)
-        for (int ch0 = q; ch0 < nch; ch0 += 16) {
+        for (int ch0 = q; ch0 < nch + 4; ch0 += 16) {
             v4i_t xv[2][2], wv[2][2];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int ch = ch0 + 8 * u;
-                    const bool ok = live[rh + r] && ch < nch;
+                    const int ch = ch0 + 8 * u - 4 * ((xodd >> (rh + r)) & 1);
+                    const bool ok = live[rh + r] && ch >= 0 && ch < nch;
                     const v4i_t zero = {0, 0, 0, 0};
                     // (non-temporal: a sample's plane row is read once, eight lanes to a cache line)
                     xv[r][u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(xrow[rh + r] + ch * 16)) : zero;
@@ -1798,6 +1816,7 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
                         awr[rh + r] = __builtin_amdgcn_sdot4(wv[r][u][e], wv[r][u][e], awr[rh + r], false);
                     }
         }
+    PM_STAMP(2);   // (the rows have been read)
     // The thread's four samples' sums over the sample's eight lanes (every lane ends up with the totals), then ONE pass
     // of the float64 bound with lane q of the eight taking sample q -- four passes with one lane in eight at work were
     // half of the instructions this kernel issues at d = 128.
@@ -1842,6 +1861,7 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
         }
     }
     __syncthreads();
+    PM_STAMP(3);   // (bounds)
     const bool all = misc[0] != 0;
     if (!all) {
         // runs of equal seeds (the samples come sorted by seed; any other order only makes more runs)
@@ -1907,6 +1927,7 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
         }
     }
     __syncthreads();
+    PM_STAMP(4);   // (marks)
     if (wave == 0) {  // compact the marked prototypes, ascending (as the sweeps do)
         uint32_t base = 0;
         uint16_t *out = ulist + (size_t)group * ulist_stride;
@@ -1941,6 +1962,7 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
             }
         }
     }
+    PM_STAMP(5);   // (list written)
 }
 
 // ---- 3. exact arg-min over the marked prototypes (float64 MFMA on gathered rows) -----------------
@@ -1953,15 +1975,6 @@ __global__ __launch_bounds__(256, 6) void prune_mark_kernel(
 // NS = stages of the ring (NS - 1 tiles in flight).  3 where the chip is full of workgroups; the 64-sample
 // workgroups of a small sample set (one or two rounds of workgroups) take as many stages as fit four
 // workgroups per CU: 6 / 5 / 4 for JTL = 1 / 2 / 3 (C2 stage 99 -> 91 us, a 125 k-row share of C4 235 -> 212).
-// (in-kernel stamps of the experiment builds: csrc/experiments.h, tools/build_variant.sh; empty in the library)
-#ifdef DBGSOM_EXPERIMENTS
-#include "experiments.h"
-#else
-#define XT_DECL
-#define XT_MARK(k)
-#define XT_MARK_ONCE(k)
-#define XT_FLUSH(JTL_, cnt_, dist_, isamp0_, Kk_)
-#endif
 #ifndef DBGSOM_QUAD_MAX
 #define DBGSOM_QUAD_MAX 3
 #endif
@@ -3081,3 +3094,9 @@ int dbgsom_bmu_filtered_counts_async(const void *workspace_dev, int64_t N, int64
 }
 
 }  // extern "C"
+
+#if defined(DBGSOM_EXPERIMENTS) && PRUNE_STAMPS
+extern "C" int dbgsom_experiment_prune_stamps(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prune_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
