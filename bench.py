@@ -76,7 +76,8 @@ def source_hash():
     h = hashlib.sha256()
     src = os.path.join(ROOT, "dbgsom_amd", "csrc")
     for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h")):
+        # (experiments.h is compiled by tools/build_variant.sh only, never into the library)
+        if name.endswith((".hip", ".h")) and name != "experiments.h":
             h.update(name.encode())
             h.update(open(os.path.join(src, name), "rb").read())
     return h.hexdigest()[:16]

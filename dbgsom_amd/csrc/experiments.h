@@ -71,7 +71,7 @@
 #endif
 #if PRUNE_STAMPS
 __device__ unsigned long long g_prune_stamps[8 * 16384];
-#define PM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_prune_stamps[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) { g_prune_stamps[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); if ((k) == 0) g_prune_stamps[8 * blockIdx.x + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffff); } } while (0)
 #else
 #define PM_STAMP(k)
 #endif

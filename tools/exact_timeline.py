@@ -84,3 +84,8 @@ for a, b in zip(bins[:-1], bins[1:]):
     act = (s_us <= mid) & (e_us > mid)
     waves = sum(((cls == c) & act).sum() * (8 if c == 3 else 4) for c in (1, 2, 3))
     print(f"  t = {mid:7.1f} us: resident workgroups {act.sum():5d} (class 3/2/1: {((cls == 3) & act).sum()}/{((cls == 2) & act).sum()}/{((cls == 1) & act).sum()}), wavefronts per CU {waves / ids.size:.1f}")
+# per XCD: the hardware deals workgroup k to XCD k % 8 whatever their pace
+xcc_ = (cu >> 16)
+for x in np.unique(xcc_):
+    m = xcc_ == x
+    print(f"  XCD {x}: {m.sum():5d} workgroups, life {np.mean(e_us[m] - s_us[m]):7.2f} us, last start {s_us[m].max():7.1f}, last end {e_us[m].max():7.1f}")

@@ -36,8 +36,10 @@ nb = min((n + 127) // 128, 16384)
 buf = np.zeros(8 * nb, dtype=np.uint64)
 rc = lib.dbgsom_experiment_prune_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(8 * nb))
 assert rc == 0, rc
-st = buf.reshape(nb, 8)[:, :6].astype(np.int64)
-st = st[(st > 0).all(axis=1)]
+raw = buf.reshape(nb, 8)
+ok_ = (raw[:, :6] > 0).all(axis=1)
+st = raw[ok_, :6].astype(np.int64)
+xcc = (raw[ok_, 6] >> np.uint64(16)).astype(int)
 t0 = st[:, 0].min()
 us = (st - t0) / 100.0
 print(f"{name}: {len(us)} workgroups; span {us[:, 5].max():.1f} us; life {np.mean(us[:, 5] - us[:, 0]):.2f} us "
@@ -49,3 +51,14 @@ bins = np.linspace(0, us[:, 5].max(), 11)
 for a, b in zip(bins[:-1], bins[1:]):
     mid = 0.5 * (a + b)
     print(f"  t = {mid:7.1f} us: resident workgroups {int(((us[:, 0] <= mid) & (us[:, 5] > mid)).sum())}")
+# lives by start time (is the ragged end made of longer-lived workgroups?)
+order_ = np.argsort(us[:, 0])
+for dec in range(10):
+    sel = order_[dec * len(us) // 10:(dec + 1) * len(us) // 10]
+    lf = us[sel, 5] - us[sel, 0]
+    ph = [np.mean(us[sel, k + 1] - us[sel, k]) for k in range(5)]
+    print(f"  started {us[sel, 0].min():6.1f} .. {us[sel, 0].max():6.1f} us: life {lf.mean():6.2f} (max {lf.max():6.2f}); phases " + " ".join(f"{v:5.2f}" for v in ph))
+# per XCD: workgroups, mean life, when its last workgroup ends
+for x in (np.unique(xcc) if raw[ok_, 6].any() else []):
+    m = xcc == x
+    print(f"  XCD {x}: {m.sum():5d} workgroups, life {np.mean(us[m, 5] - us[m, 0]):6.2f} us, last start {us[m, 0].max():6.1f}, last end {us[m, 5].max():6.1f}")
