@@ -579,7 +579,7 @@ class Harness:
         """W untimed steps, then exactly `steps` timed ones bracketed by barrier + synchronize, with
         the context's event instrumentation OFF (ten event records per epoch are worth 2-5 % at small
         shapes); then min(steps, 5) more steps, untimed, with it ON for the per-phase HIP-event
-        times (events on the context's stream).  Returns (max-over-ranks seconds, mean ms per phase)."""
+        times (events on the context's stream).  Returns (max-over-ranks seconds, median ms per phase)."""
         be.phase_log = None
         be._set("timing", 0)
         for _ in range(warmup):
@@ -603,7 +603,9 @@ class Harness:
             step_fn()
         log, be.phase_log = np.array(be.phase_log), None
         be._set("timing", 0)
-        return elapsed, dict(zip(PHASES, log.mean(axis=0).tolist()))
+        # (the median of the instrumented steps: one of them may be a trial of the policy -- the other form of the
+        #  exact stage on a C5 shard takes three times the usual -- and a mean carries it into every roofline)
+        return elapsed, dict(zip(PHASES, np.median(log, axis=0).tolist()))
 
 
 def frozen_map_regime(h, algorithm, X, W0, hop, sigma, gamma, steps=None, warmup=None, assignments=False):
