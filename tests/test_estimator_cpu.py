@@ -295,3 +295,23 @@ def test_finite_check_keyword_follows_the_installed_scikit_learn():
     assert SomVQ(backend=OracleBackend())._finite_check_on_device() is False
     with pytest.raises(ValueError):                                  # the host check, as ever
         SomVQ(backend=OracleBackend(), n_iter=3).fit(np.array([[np.inf, 1.0]] * 8))
+
+
+def test_bench_counts_the_products_the_exact_stage_executes():
+    """bench.list_flops prices the exact stage's executed products by the kernel's rule (filter.hip,
+    subset_exact_workgroup: steps of 16 / 32 / 48 entries by class; per step whole 16-prototype tiles and, for a last
+    tile with up to 12 entries, groups of four): against a step-by-step restatement for every list length."""
+    import bench
+
+    for c in range(1, 400):
+        cls = 1 if c <= 16 else (2 if c <= 32 else 3)
+        left, executed = c, 0
+        while left > 0:
+            e = min(16 * cls, left)
+            tiles = (e + 15) // 16
+            rem = e - 16 * (tiles - 1)
+            executed += 16 * (tiles - 1) + 4 * ((rem + 3) // 4) if rem <= 12 else 16 * tiles
+            left -= e
+        useful, padded = bench.list_flops(np.array([c]), 128, 16)
+        assert useful == 2.0 * 128 * c * 16
+        assert padded == 2.0 * 128 * executed * 16, (c, padded / (2.0 * 128 * 16), executed)
